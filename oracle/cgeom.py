@@ -1,0 +1,55 @@
+"""ctypes view of the plain-C oracle ``oracle/c/geom_oracle.c`` (test infrastructure)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .build_oracle import build
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def linspace(start, end, n):
+    out = np.empty(n, np.float32)
+    lib().orc_linspace(C.c_float(start), C.c_float(end), C.c_int(n), _p(out))
+    return out
+
+
+def homo_warp(U, theta, out_hw, want_idx=True, want_out=True):
+    """U [B,C,H,W] f32, theta [B,3,3] -> (out [B,C,oh,ow] f32, idx [B,oh,ow,4] i32 = x0,x1,y0,y1)."""
+    U = np.ascontiguousarray(U, np.float32)
+    theta = np.ascontiguousarray(theta, np.float32).reshape(-1, 9)
+    B, Cc, H, W = U.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out = np.empty((B, Cc, oh, ow), np.float32) if want_out else None
+    idx = np.empty((B, oh, ow, 4), np.int32) if want_idx else None
+    lib().orc_homo_warp(_p(U), _p(theta), _p(out), _p(idx, C.c_int32), B, Cc, H, W, oh, ow)
+    return out, idx
+
+
+def range_map(flow):
+    flow = np.ascontiguousarray(flow, np.float32)
+    B, _, H, W = flow.shape
+    out = np.empty((B, 1, H, W), np.float32)
+    lib().orc_range_map(_p(flow), _p(out), B, H, W)
+    return out
+
+
+def morph_open(mask, ksz=19):
+    mask = np.ascontiguousarray(mask, np.float32)
+    B, Cc, H, W = mask.shape
+    out = np.empty_like(mask)
+    lib().orc_morph_open(_p(mask), _p(out), B * Cc, H, W, ksz)
+    return out
