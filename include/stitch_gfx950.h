@@ -1,0 +1,154 @@
+/* libstitch_gfx950.so -- C-ABI of the MI355X-native stitching hot path.
+ *
+ * The reference (gargatik/Seamless-Through-Breaking..., 100 % Python) has no native interface for
+ * this path: every operator below replaces stock PyTorch ops called from
+ * core/flowHomoAdpater.py:FlowHomoAdpater.forward (the drop-in boundary).  Each entry
+ * point cites the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch CUDA tensor .data_ptr()), fp32 unless
+ *     stated, 16-byte aligned bases; no allocation, no ownership transfer, no global state
+ *   - `stream` is a hipStream_t (0 = default stream); all calls are asynchronous on it
+ *   - activations are channels-last: [B, H, W, C] with a row stride `ld*` (floats) >= C, so a
+ *     channel slice of a wider buffer is addressable (concatenation = column offset)
+ *   - return 0 on success, ST_EINVAL (1001) for a rejected argument, otherwise a hipError_t value
+ */
+#ifndef STITCH_GFX950_H
+#define STITCH_GFX950_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dense contractions -------------------------------------------------------------------- */
+typedef struct st_gemm_desc {
+    const float* a;        /* activations, NHWC [B,H,W,ldx] (plain matrix: H=1, W=M, kh=kw=1)      */
+    const float* w;        /* weights [N, K] row-major, K ordered (ky, kx, c), row stride ldw       */
+    float* c;              /* output [M, ldc], M = B*Ho*Wo                                          */
+    const float* bias;     /* [N] or NULL                                                           */
+    const float* aux0;     /* pre-activation addend [*, ld_aux0] or NULL; row = (m / aux0_row_div) % aux0_row_mod */
+    const float* aux1;     /* epilogue operand [M, ld_aux1] or NULL                                 */
+    const float* aux2;     /* epilogue operand [M, ld_aux2] or NULL                                 */
+    const float* scale_ptr;/* device scalar for ST_EPI_AXPY or NULL                                 */
+    int32_t M, N, K;       /* K = kh*kw*Cin                                                         */
+    int32_t H, W, Cin, ldx;
+    int32_t kh, kw, sh, sw, ph, pw, Ho, Wo;
+    int32_t ldw, ldc, ld_aux0, ld_aux1, ld_aux2;
+    int32_t aux0_row_div, aux0_row_mod;   /* 0/1 = identity row mapping                            */
+    int32_t act;           /* 0 none, 1 relu, 2 gelu(erf), 3 sigmoid, 4 tanh                        */
+    int32_t epi;           /* 0 store, 1 +aux1, 2 *aux1, 3 GRU blend, 4 aux1 + *scale_ptr * v       */
+    float alpha;           /* v = act(alpha*acc + bias + aux0)                                      */
+    int32_t batch;         /* grid.z batches (0/1 = single)                                         */
+    int64_t batch_stride_a, batch_stride_w, batch_stride_c;   /* in floats                          */
+    int32_t tile_cfg;      /* 0 = auto; 1: 128x128, 2: 128x64, 3: 64x64, 4: 128x32                 */
+} st_gemm_desc;
+
+/* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.
+ *   core/FlowFormer/PerCostFormer3/encoder.py:359-369 (corr), :60-95 (PatchEmbed convs),
+ *   gru.py:44-59,246-254,5-13 (SepConvGRU, motion encoder, heads), gma.py:54-76,102-115,
+ *   twins.py:253-392,587-680 (q/k/v/proj/sr/MLP), core/UDIS2/Homography/network.py:18-46,103-137. */
+int st_conv_gemm(const st_gemm_desc* desc, void* stream);
+
+/* sizeof(st_gemm_desc) as compiled into the library (binding self-check; returns the size). */
+int st_abi_gemm_desc_size(void);
+
+/* All-pairs correlation volume, MemoryEncoder.corr (encoder.py:359-369):
+ *   f1, f2 [B, N, C] channels-last features -> vol [B, N1, N2] = f1 . f2^T (no scaling). */
+int st_corr_volume(const float* f1, const float* f2, float* vol, int32_t B, int32_t N1, int32_t N2,
+                   int32_t C, void* stream);
+
+/* ---- row-wise network ops (channels-last rows) ------------------------------------------------ */
+/* nn.LayerNorm over the last dim (encoder.py:58,140-141; twins.py:752-790, eps 1e-5 / 1e-6).        */
+int st_layernorm(const float* x, int32_t ldx, const float* w, const float* b, float* out, int32_t ldo,
+                 int32_t rows, int32_t C, float eps, void* stream);
+/* in-place softmax over rows of length C <= 4096 (gma.py:72 `sim.softmax(dim=-1)`).                */
+int st_softmax_rows(float* x, int32_t ld, int32_t rows, int32_t C, void* stream);
+/* F.normalize(p=2, dim=C) on NHWC rows (core/UDIS2/Homography/network.py:150-151).                  */
+int st_l2norm_rows(const float* x, float* out, int32_t rows, int32_t C, void* stream);
+/* nn.MaxPool2d on NHWC (network.py:22,28,34; torchvision resnet maxpool 3/2/1).                     */
+int st_maxpool_nhwc(const float* x, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                    int32_t s, int32_t p, void* stream);
+/* PEG PosConv: depthwise 3x3 + bias + identity (twins.py:793-808); w [9, C].                        */
+int st_dwconv3x3_residual(const float* x, const float* w, const float* bias, float* out, int32_t B,
+                          int32_t H, int32_t W, int32_t C, void* stream);
+/* LinearPositionEmbeddingSine (attention.py:156-161); coords [rows, ldc]=(x,y) or implicit grid
+ * (row -> (row % Wg, row / Wg), optionally modulo ws), value*cscale + coff; write or accumulate.   */
+int st_sine_pe(float* out, int32_t ld, int32_t rows, int32_t dim, const float* coords, int32_t ldc,
+               int32_t Wg, int32_t ws, float cscale, float coff, int32_t accumulate, void* stream);
+/* Multi-head softmax attention, element (b, t, h, e) at base + b*bs + t*ts + h*D + e (floats).
+ *   _small : one thread per query, K/V from L2 (attention.py:9-68; 8 latents / 1x8 decoder query)
+ *   _kvlds : K/V slab (Nk <= 256) staged in LDS (GSA: twins.py:336-392,633-680)                     */
+int st_attention_small(const float* q, int64_t q_bs, int64_t q_ts, const float* k, int64_t k_bs, int64_t k_ts,
+                       const float* v, int64_t v_bs, int64_t v_ts, float* out, int64_t o_bs, int64_t o_ts,
+                       int32_t B, int32_t heads, int32_t Nq, int32_t Nk, int32_t D, float scale, void* stream);
+int st_attention_kvlds(const float* q, int64_t q_bs, int64_t q_ts, const float* k, int64_t k_bs, int64_t k_ts,
+                       const float* v, int64_t v_bs, int64_t v_ts, float* out, int64_t o_bs, int64_t o_ts,
+                       int32_t B, int32_t heads, int32_t Nq, int32_t Nk, int32_t D, float scale, void* stream);
+/* 7x7-window attention (LSA: twins.py:253-304,587-631); q/k/v pad tables [ws*ws, heads*D] hold the
+ * projections of a zero-padded token at each window position.                                      */
+int st_window_attention(const float* q, const float* k, const float* v, int64_t bs, int64_t ts,
+                        const float* qpad, const float* kpad, const float* vpad, float* out, int64_t o_bs,
+                        int64_t o_ts, int32_t B, int32_t H, int32_t W, int32_t heads, int32_t D, int32_t ws,
+                        float scale, void* stream);
+/* CCL: 3x3 patch correlation + softmax(10 x) + soft-argmax (network.py:147-199) from the all-pairs
+ * product G [B, P, P] of the normalised features; out [B, P, ldo] = (flow_w, flow_h, 0...).         */
+int st_ccl_softargmax(const float* G, float* out, int32_t ldo, int32_t B, int32_t h, int32_t w, void* stream);
+int st_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t rows, int32_t cols, void* stream);
+/* NCHW image -> channels-last rows with v = mul*(x/div) - sub (flowHomoAdpater.py:55-56,
+ * transformer.py:53-54); channels C..ldo-1 are zero.                                               */
+int st_prep_image(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t ldo,
+                  float mul, float div, float sub, void* stream);
+
+/* ---- FlowFormer decoder gathers --------------------------------------------------------------- */
+int st_coords_grid(float* out, int32_t B, int32_t H, int32_t W, void* stream);          /* decoder.py:22-29 */
+int st_flow_from_coords(const float* coords1, float* flow4, int32_t ld4, float* dst2, int32_t ld2, int32_t B,
+                        int32_t H, int32_t W, void* stream);                             /* decoder.py:321   */
+/* encode_flow_token + bilinear_sampler (decoder.py:242-260, core/utils/utils.py:62-76).              */
+int st_cost_lookup(const float* maps, const float* coords, float* out, int32_t ldo, int32_t Nq, int32_t H2,
+                   int32_t W2, int32_t r, void* stream);
+/* upsample_flow (decoder.py:214-225): mask [B*H*W, ldm>=576] -> out NCHW [B,2,8H,8W].              */
+int st_convex_upsample(const float* coords1, const float* mask, int32_t ldm, float* out, int32_t B, int32_t H,
+                       int32_t W, void* stream);
+
+/* ---- geometric stage (NCHW images; bit-exact integer sample indices) --------------------------- */
+/* tensor_DLT (core/udis_utils/torch_DLT.py:17-45): src [4,2] shared corners, dst = src +
+ * motion[B,4,2]*(mscale_x, mscale_y), both divided by `div` -> H [B,3,3].                           */
+int st_dlt4(const float* src4x2, const float* motion, float* H, int32_t B, float mscale_x, float mscale_y,
+            float div, void* stream);
+/* out[b] = L @ (invert ? X[b]^-1 : X[b]) @ R (flowHomoAdpater.py:108,112,226,307).                  */
+int st_mat3_sandwich(const float* L, const float* X, const float* R, float* out, int32_t B, int32_t invert,
+                     void* stream);
+/* torch_homo_transform.transformer (core/udis_utils/torch_homo_transform.py:5-151); the last n_ones
+ * output channels are the warp of an all-ones image; idx (optional) [B,oh,ow,4] = x0,x1,y0,y1.      */
+int st_homo_warp(const float* U, const float* theta, float* out, int32_t* idx, int32_t B, int32_t C,
+                 int32_t n_ones, int32_t H, int32_t W, int32_t oh, int32_t ow, void* stream);
+/* get_rigid_mesh + H2Mesh + min/max (core/warp_utils.py:10-34, flowHomoAdpater.py:254-266).          */
+int st_mesh_bounds(const float* H, float* out4, int32_t B, float width, float height, int32_t gw, int32_t gh,
+                   void* stream);
+/* warp() = grid_sample(bilinear, zeros, align_corners=True) at pix+flow (core/warp_utils.py:54-80). */
+int st_flow_warp(const float* x, const float* flow, const float* mul, float* out, int32_t B, int32_t C,
+                 int32_t H, int32_t W, void* stream);
+/* F.interpolate bilinear: resize_flow (warp_utils.py:38-46) / Resize((512,512)) (flowHomoAdpater.py:14). */
+int st_resize_bilinear(const float* x, float* out, int32_t planes, int32_t H, int32_t W, int32_t oh, int32_t ow,
+                       int32_t align_corners, float div0, float div1, int32_t ndiv, void* stream);
+/* compute_range_map (core/warp_utils.py:114-175), deterministic fixed-point splat.                  */
+int st_range_map(const float* flow, void* scratch_u64, float* out, int32_t B, int32_t H, int32_t W, void* stream);
+int st_occlusion_from_range(const float* range, float* out, int64_t n, int32_t threshold, void* stream);
+/* preprocess_occlusion_mask (flowHomoAdpater.py:18-35); scratch: 2*N*H*W bytes.                     */
+int st_morph_open(const float* mask, float* out, void* scratch_u8x2, int32_t N, int32_t H, int32_t W,
+                  int32_t ksz, void* stream);
+int st_eval_finish(float* final6, const float* occ, float* overlap, int32_t B, int32_t H, int32_t W, void* stream);
+int st_blend(const float* homo1, const float* homo2, float* fin, const float* occ, float* output2, float* mask1,
+             float* mask2, uint8_t* blend, int32_t h, int32_t w, void* stream);          /* :339-360 */
+int st_mean_threshold(const float* x, float* out, int32_t B, int32_t C, int32_t H, int32_t W, float thr,
+                      void* stream);                                                      /* :233-234 */
+/* UDIS2 TPS transformer (core/udis_utils/torch_tps_transform.py:7-190): fp64 solve -> T [B,2,N+3],
+ * then grid + 4-tap gather.  work_f64: B*(N+3)*(N+5) doubles.                                       */
+int st_tps_solve_grid(const float* U, const float* source, const float* target, void* work_f64, float* T,
+                      float* out, int32_t* idx, int32_t B, int32_t C, int32_t H, int32_t W, int32_t N,
+                      int32_t oh, int32_t ow, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+"""ctypes binding of libstitch_gfx950.so (the C-ABI declared in include/stitch_gfx950.h).
+
+Argument types are parsed from the header so the binding cannot drift from the declarations.
+There is no fallback: if the shared library is missing or a symbol is absent, import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libstitch_gfx950.so")
+HEADER = os.path.join(HERE, "..", "include", "stitch_gfx950.h")
+
+_SCALARS = {"int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float, "int": C.c_int}
+
+
+class GemmDesc(C.Structure):
+    """Mirror of ``st_gemm_desc`` (include/stitch_gfx950.h)."""
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("a", "w", "c", "bias", "aux0", "aux1", "aux2", "scale_ptr")]
+        + [(n, C.c_int32) for n in ("M", "N", "K", "H", "W", "Cin", "ldx", "kh", "kw", "sh", "sw", "ph", "pw", "Ho",
+                                    "Wo", "ldw", "ldc", "ld_aux0", "ld_aux1", "ld_aux2", "aux0_row_div", "aux0_row_mod",
+                                    "act", "epi")]
+        + [("alpha", C.c_float), ("batch", C.c_int32)]
+        + [(n, C.c_int64) for n in ("batch_stride_a", "batch_stride_w", "batch_stride_c")]
+        + [("tile_cfg", C.c_int32)]
+    )
+
+
+def declared_functions(header=HEADER):
+    """{name: [ctypes argtypes]} for every ``int st_*(...)`` declaration in the header."""
+    src = open(header).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\bint\s+(st_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        args = []
+        for a in m.group(2).split(","):
+            a = " ".join(a.split())
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                args.append(C.c_void_p)
+            else:
+                args.append(_SCALARS[a.replace("const ", "").split(" ")[0]])
+        out[m.group(1)] = args
+    return out
+
+
+class StitchError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python __graft_entry__.py or "
+            f"python {os.path.join(HERE, 'build.py')}). There is no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in declared_functions().items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"libstitch_gfx950.so does not export {name} (declared in stitch_gfx950.h)") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise StitchError(f"{what} failed with code {rc}" + (" (ST_EINVAL: rejected argument)" if rc == 1001 else " (hipError_t)"))

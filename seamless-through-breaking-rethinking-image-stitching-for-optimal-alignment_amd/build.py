@@ -1,0 +1,48 @@
+"""Build libstitch_gfx950.so (hipcc, gfx950 only) in-tree: ``python <pkg>/build.py``."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libstitch_gfx950.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# geom.hip pins every fp32 rounding (bit-exact sample indices): no fma contraction there
+SOURCES = {"gemm.hip": [], "nn.hip": [], "flowops.hip": [], "geom.hip": ["-ffp-contract=off"]}
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "stitch_gfx950.h")]
+    objs, jobs = [], []
+    os.makedirs(os.path.join(CSRC, "_obj"), exist_ok=True)
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, "_obj", src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])
+    if jobs:
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(run, jobs))
+    if jobs or _stale(OUT, objs):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,310 @@
+// fp32 implicit-GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain).
+//
+//   C[m, n] = epilogue( alpha * sum_k A(m, k) * Wt[n, k] + bias[n] )
+//
+// A is an NHWC activation read through convolution addressing (kh x kw window, stride, zero
+// padding); a plain row-major matrix is the 1x1 case.  Wt is [N, K] row-major with
+// K = kh*kw*Cin ordered (ky, kx, c) -- the layout nn.Linear already has and the layout the host
+// prepacks conv weights into.  Both operand tiles are K-contiguous in LDS ([rows][BK+4] floats, the
+// +4 pad makes the 16-B fragment reads conflict-free); each lane fetches 4 consecutive k of its row
+// with one ds_read_b128 and feeds them to 4 consecutive MFMAs, lane half h taking k = 8j+4h+t for
+// both operands so the contraction pairs up without any transposition.
+//
+// Replaces (reference, /root/reference): every F.conv2d / nn.Linear / einsum contraction on the
+// FlowHomoAdpater path, e.g. core/FlowFormer/PerCostFormer3/encoder.py:359-369 (all-pairs corr),
+// gru.py:44-59 (SepConvGRU), core/UDIS2/Homography/network.py:103-137 (ResNet-50 + regressor).
+#include "common.h"
+#include "../../include/stitch_gfx950.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define LDS_LD (BK + 4)
+
+template <int WARPS_M, int WARPS_N, int TM, int TN, bool VEC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
+    constexpr int BM = WARPS_M * TM * 32;
+    constexpr int BN = WARPS_N * TN * 32;
+    static_assert(WARPS_M * WARPS_N == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                      // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;    // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+    // batch (grid.z) offsets
+    const int bz = blockIdx.z;
+    const float* __restrict__ X = d.a + (size_t)bz * d.batch_stride_a;
+    const float* __restrict__ Wt = d.w + (size_t)bz * d.batch_stride_w;
+    float* __restrict__ C = d.c + (size_t)bz * d.batch_stride_c;
+
+    // XCD-aware tile order: consecutive block ids are dealt round-robin over the 8 XCDs, so give
+    // each XCD a contiguous run of tiles (neighbouring tiles share operand panels in its L2).
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % ntn, tile_m = bid / ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int K = d.K;
+    const int kcol = (tid & 7) * 4;   // this thread's float4 column inside a BK chunk
+    const int rrow = tid >> 3;        // 0..31
+
+    // per-thread A rows: decode m -> (b, oy, ox) once
+    constexpr int AP = BM / 32, BP = BN / 32;
+    int a_pix[AP];      // pixel index of (b, iy0, ix0) top-left, or <0 row invalid
+    int a_iy0[AP], a_ix0[AP], a_b[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        const int m = m0 + rrow + 32 * p;
+        if (m < d.M) {
+            const int hw = d.Ho * d.Wo;
+            const int b = m / hw, r = m - b * hw;
+            const int oy = r / d.Wo, ox = r - oy * d.Wo;
+            a_b[p] = b; a_iy0[p] = oy * d.sh - d.ph; a_ix0[p] = ox * d.sw - d.pw;
+            a_pix[p] = 0;
+        } else { a_pix[p] = -1; a_b[p] = 0; a_iy0[p] = 0; a_ix0[p] = 0; }
+    }
+
+    float4 ra[AP], rb[BP];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kcol;
+        if constexpr (VEC) {
+            int kyx = 0, c = k, ky = 0, kx = 0;
+            if (d.kh * d.kw > 1) { kyx = k / d.Cin; c = k - kyx * d.Cin; ky = kyx / d.kw; kx = kyx - ky * d.kw; }
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int iy = a_iy0[p] + ky, ix = a_ix0[p] + kx;
+                if (a_pix[p] >= 0 && k < K && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
+                    v = *reinterpret_cast<const float4*>(X + ((size_t)(a_b[p] * d.H + iy) * d.W + ix) * d.ldx + c);
+                ra[p] = v;
+            }
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                const int n = n0 + rrow + 32 * p;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < d.N && k < K) v = *reinterpret_cast<const float4*>(Wt + (size_t)n * d.ldw + k);
+                rb[p] = v;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ke = k + e;
+                    float x = 0.f;
+                    if (a_pix[p] >= 0 && ke < K) {
+                        const int kyx = ke / d.Cin, c = ke - kyx * d.Cin;
+                        const int ky = kyx / d.kw, kx = kyx - ky * d.kw;
+                        const int iy = a_iy0[p] + ky, ix = a_ix0[p] + kx;
+                        if (iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
+                            x = X[((size_t)(a_b[p] * d.H + iy) * d.W + ix) * d.ldx + c];
+                    }
+                    v[e] = x;
+                }
+                ra[p] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                const int n = n0 + rrow + 32 * p;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (n < d.N && k + e < K) ? Wt[(size_t)n * d.ldw + k + e] : 0.f;
+                rb[p] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p)
+            *reinterpret_cast<float4*>(As + ((size_t)buf * BM + rrow + 32 * p) * LDS_LD + kcol) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BP; ++p)
+            *reinterpret_cast<float4*>(Bs + ((size_t)buf * BN + rrow + 32 * p) * LDS_LD + kcol) = rb[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = (K + BK - 1) / BK;
+    const int li = lane & 31, lh = lane >> 5;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);   // global loads in flight under the MFMAs
+        const float* Ab = As + ((size_t)buf * BM + wm * TM * 32 + li) * LDS_LD + 4 * lh;
+        const float* Bb = Bs + ((size_t)buf * BN + wn * TN * 32 + li) * LDS_LD + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < BK / 8; ++j) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + 8 * j);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) bf[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDS_LD + 8 * j);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[jn].x, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[jn].y, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[jn].z, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li] of the 32x32 tile
+    const float alpha = d.alpha;
+    const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * TN * 32 + jn * 32 + li;
+        if (n >= d.N) continue;
+        const float bv = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= d.M) continue;
+                float v = acc[i][jn][r] * alpha + bv;
+                if (d.aux0) {
+                    int ar = m;
+                    if (d.aux0_row_div > 1) ar = m / d.aux0_row_div;
+                    if (d.aux0_row_mod > 0) ar = ar % d.aux0_row_mod;
+                    v += d.aux0[(size_t)ar * d.ld_aux0 + n];
+                }
+                v = st_act(v, d.act);
+                switch (d.epi) {
+                    case ST_EPI_ADD: v += d.aux1[(size_t)m * d.ld_aux1 + n]; break;
+                    case ST_EPI_MUL: v *= d.aux1[(size_t)m * d.ld_aux1 + n]; break;
+                    case ST_EPI_GRU: {
+                        const float z = d.aux1[(size_t)m * d.ld_aux1 + n], h = d.aux2[(size_t)m * d.ld_aux2 + n];
+                        v = (1.0f - z) * h + z * v;
+                    } break;
+                    case ST_EPI_AXPY: v = d.aux1[(size_t)m * d.ld_aux1 + n] + sc * v; break;
+                    default: break;
+                }
+                C[(size_t)m * d.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// Skinny GEMM (M <= 8 rows, e.g. the batch-1 regression head): weight-read bound, one wave per
+// output column, K split across the lanes with 16-B loads, wave-shuffle reduction.
+template <int MR>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const st_gemm_desc d) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= d.N) return;
+    const float* w = d.w + (size_t)wave * d.ldw;
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+    for (int k = lane * 4; k < d.K; k += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + k);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < d.M) {
+                const float4 av = *reinterpret_cast<const float4*>(d.a + (size_t)m * d.ldx + k);
+                acc[m] = fmaf(av.x, wv.x, acc[m]); acc[m] = fmaf(av.y, wv.y, acc[m]);
+                acc[m] = fmaf(av.z, wv.z, acc[m]); acc[m] = fmaf(av.w, wv.w, acc[m]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = wave_sum(acc[m]);
+    if (lane == 0) {
+        const float bv = d.bias ? d.bias[wave] : 0.f;
+        for (int m = 0; m < d.M && m < MR; ++m) d.c[(size_t)m * d.ldc + wave] = st_act(acc[m] * d.alpha + bv, d.act);
+    }
+}
+
+template <int WARPS_M, int WARPS_N, int TM, int TN>
+static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
+    constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    dim3 grid(ntm * ntn, 1, d.batch > 0 ? d.batch : 1);
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    if (vec) {
+        auto k = conv_gemm_kernel<WARPS_M, WARPS_N, TM, TN, true>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, d);
+    } else {
+        auto k = conv_gemm_kernel<WARPS_M, WARPS_N, TM, TN, false>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, d);
+    }
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
+    if (!desc) return ST_EINVAL;
+    st_gemm_desc d = *desc;
+    if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
+    if (d.kh <= 0 || d.kw <= 0 || d.K != d.kh * d.kw * d.Cin) return ST_EINVAL;
+    if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
+    if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool aligned = ((uintptr_t)d.a % 16 == 0) && ((uintptr_t)d.w % 16 == 0) && (d.ldx % 4 == 0) &&
+                         (d.ldw % 4 == 0) && (d.Cin % 4 == 0) &&
+                         (d.batch_stride_a % 4 == 0) && (d.batch_stride_w % 4 == 0);
+    const int batch = d.batch > 0 ? d.batch : 1;
+    if (d.M <= 8 && d.kh == 1 && d.kw == 1 && aligned && batch == 1 && d.epi == ST_EPI_STORE && !d.aux0 && d.H * d.W == d.M) {
+        hipLaunchKernelGGL(skinny_gemm_kernel<8>, dim3((d.N * 64 + 255) / 256), dim3(256), 0, s, d);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
+    // tile choice: largest tile that still yields >= ~1.5 waves of workgroups over the 256 CUs
+    auto nwg = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };
+    int cfg = d.tile_cfg;
+    if (cfg == 0) {
+        if (d.N <= 32) cfg = 4;
+        else if (d.N > 64 && nwg(128, 128) >= 384) cfg = 1;
+        else if (nwg(128, 64) >= 384) cfg = 2;
+        else cfg = 3;
+    }
+    switch (cfg) {
+        case 1: return launch_cfg<2, 2, 2, 2>(d, aligned, s);
+        case 2: return launch_cfg<2, 2, 2, 1>(d, aligned, s);
+        case 3: return launch_cfg<2, 2, 1, 1>(d, aligned, s);
+        case 4: return launch_cfg<4, 1, 1, 1>(d, aligned, s);
+        default: return ST_EINVAL;
+    }
+}
+
+// All-pairs correlation volume = batched A . B^T on the same MFMA core (K = C = 256 at 512^2).
+extern "C" int st_corr_volume(const float* f1, const float* f2, float* vol, int32_t B, int32_t N1, int32_t N2,
+                              int32_t C, void* stream) {
+    if (!f1 || !f2 || !vol || B <= 0 || N1 <= 0 || N2 <= 0 || C <= 0) return ST_EINVAL;
+    st_gemm_desc d = {};
+    d.a = f1; d.w = f2; d.c = vol;
+    d.M = N1; d.N = N2; d.K = C;
+    d.H = 1; d.W = N1; d.Cin = C; d.ldx = C;
+    d.kh = d.kw = 1; d.sh = d.sw = 1; d.ph = d.pw = 0; d.Ho = 1; d.Wo = N1;
+    d.ldw = C; d.ldc = N2; d.alpha = 1.0f;
+    d.batch = B; d.batch_stride_a = (int64_t)N1 * C; d.batch_stride_w = (int64_t)N2 * C;
+    d.batch_stride_c = (int64_t)N1 * N2;
+    return st_conv_gemm(&d, stream);
+}
+
+// ABI self-check for bindings: size of st_gemm_desc as this library was compiled.
+extern "C" int st_abi_gemm_desc_size(void) { return (int)sizeof(st_gemm_desc); }

@@ -1,0 +1,588 @@
+// Row-wise / window / small-attention kernels of the FlowFormer++ and UDIS2 networks on gfx950.
+// HBM-bound elementwise and reduction work: 16-B accesses where the layout allows, wave-shuffle
+// reductions (64 lanes), K/V tiles staged in LDS for the attention variants.
+#include "common.h"
+#include "../../include/stitch_gfx950.h"
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (nn.LayerNorm; reference e.g. encoder.py:58,156-172, twins.py:787)
+// one wave per row, C <= 64*16
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ out, int ldo,
+                                                        int rows, int C, float eps) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < C ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        const float dlt = c < C ? v[i] - mean : 0.f;
+        q += dlt * dlt;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    float* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) orow[c] = (v[i] - mean) * rstd * w[c] + b[c];
+    }
+}
+
+extern "C" int st_layernorm(const float* x, int32_t ldx, const float* w, const float* b, float* out, int32_t ldo,
+                            int32_t rows, int32_t C, float eps, void* stream) {
+    if (!x || !w || !b || !out || rows <= 0 || C <= 0 || C > 1024) return ST_EINVAL;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, out,
+                       ldo, rows, C, eps);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// In-place row softmax (GMA attention, gma.py:72): one workgroup per row, row kept in registers.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int ld, int C) {
+    __shared__ float red[8];
+    float* xr = x + (size_t)blockIdx.x * ld;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    float v[16];                      // C <= 4096
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = t + 256 * i;
+        v[i] = c < C ? xr[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = t + 256 * i;
+        v[i] = c < C ? expf(v[i] - mx) : 0.f;
+        s += v[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[4 + wv] = s;
+    __syncthreads();
+    s = (red[4] + red[5]) + (red[6] + red[7]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = t + 256 * i;
+        if (c < C) xr[c] = v[i] / s;
+    }
+}
+
+extern "C" int st_softmax_rows(float* x, int32_t ld, int32_t rows, int32_t C, void* stream) {
+    if (!x || rows <= 0 || C <= 0 || C > 4096) return ST_EINVAL;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, C);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.normalize(p=2, dim=channel) on NHWC rows (network.py:150-151): x / max(||x||, 1e-12)
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int C) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c] * xr[c];
+    const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int c = lane; c < C; c += 64) out[(size_t)row * C + c] = xr[c] / nrm;
+}
+
+extern "C" int st_l2norm_rows(const float* x, float* out, int32_t rows, int32_t C, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0) return ST_EINVAL;
+    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, out, rows, C);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d on NHWC (network.py:22-35 2x2/2, torchvision resnet maxpool 3x3/2 pad 1)
+__global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C,
+                               int k, int s, int p, int Ho, int Wo) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    if (idx >= total) return;
+    const int c = idx % C;
+    size_t r = idx / C;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho;
+    const int b = r / Ho;
+    float m = -INFINITY;
+    for (int a = 0; a < k; ++a)
+        for (int e = 0; e < k; ++e) {
+            const int iy = oy * s - p + a, ix = ox * s - p + e;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) m = fmaxf(m, x[(((size_t)b * H + iy) * W + ix) * C + c]);
+        }
+    out[idx] = m;
+}
+
+extern "C" int st_maxpool_nhwc(const float* x, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                               int32_t s, int32_t p, void* stream) {
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0) return ST_EINVAL;
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, B, H, W, C, k,
+                       s, p, Ho, Wo);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PEG: depthwise 3x3 (pad 1) + bias + identity on NHWC tokens (twins.py:793-808). w: [9, C].
+__global__ void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                 float* __restrict__ out, int B, int H, int W, int C) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 granules
+    const int C4 = C >> 2;
+    const size_t total = (size_t)B * H * W * C4;
+    if (idx >= total) return;
+    const int c = (idx % C4) * 4;
+    size_t r = idx / C4;
+    const int ox = r % W; r /= W;
+    const int oy = r % H;
+    const int b = r / H;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int iy = oy - 1 + a, ix = ox - 1 + e;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const float4 xv = *reinterpret_cast<const float4*>(x + (((size_t)b * H + iy) * W + ix) * C + c);
+            const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)(a * 3 + e) * C + c);
+            acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
+            acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+        }
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+    const float4 idt = *reinterpret_cast<const float4*>(x + (((size_t)b * H + oy) * W + ox) * C + c);
+    float4 o;
+    o.x = (acc.x + bv.x) + idt.x; o.y = (acc.y + bv.y) + idt.y;
+    o.z = (acc.z + bv.z) + idt.z; o.w = (acc.w + bv.w) + idt.w;
+    *reinterpret_cast<float4*>(out + (((size_t)b * H + oy) * W + ox) * C + c) = o;
+}
+
+extern "C" int st_dwconv3x3_residual(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t H,
+                                     int32_t W, int32_t C, void* stream) {
+    if (!x || !w || !bias || !out || C % 4) return ST_EINVAL;
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, B,
+                       H, W, C);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LinearPositionEmbeddingSine (attention.py:156-161): literal 3.14, bands k/200, layout
+// [sin x | cos x | sin y | cos y].  Coordinates come either from `coords` ([rows, ldc] = x, y) or
+// from the row index on a Wg-wide grid (optionally window-local modulo ws), scaled + offset.
+__global__ void sine_pe_kernel(float* __restrict__ out, int ld, int rows, int dim, const float* __restrict__ coords,
+                               int ldc, int Wg, int ws, float cscale, float coff, int accumulate) {
+    const int q = dim >> 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * q) return;
+    const int f = idx % q, row = idx / q;
+    float x, y;
+    if (coords) { x = coords[(size_t)row * ldc]; y = coords[(size_t)row * ldc + 1]; }
+    else {
+        int gx = row % Wg, gy = row / Wg;
+        if (ws > 0) { gx %= ws; gy %= ws; }
+        x = (float)gx * cscale + coff; y = (float)gy * cscale + coff;
+    }
+    const float fb = (float)f;
+    const float ax = ((3.14f * x) * fb) * 0.005f, ay = ((3.14f * y) * fb) * 0.005f;
+    float* o = out + (size_t)row * ld;
+    const float v0 = sinf(ax), v1 = cosf(ax), v2 = sinf(ay), v3 = cosf(ay);
+    if (accumulate) { o[f] += v0; o[q + f] += v1; o[2 * q + f] += v2; o[3 * q + f] += v3; }
+    else { o[f] = v0; o[q + f] = v1; o[2 * q + f] = v2; o[3 * q + f] = v3; }
+}
+
+extern "C" int st_sine_pe(float* out, int32_t ld, int32_t rows, int32_t dim, const float* coords, int32_t ldc, int32_t Wg,
+                          int32_t ws, float cscale, float coff, int32_t accumulate, void* stream) {
+    if (!out || rows <= 0 || dim <= 0 || dim % 4 || (!coords && Wg <= 0)) return ST_EINVAL;
+    const size_t total = (size_t)rows * (dim / 4);
+    hipLaunchKernelGGL(sine_pe_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, ld, rows, dim,
+                       coords, ldc, Wg, ws, cscale, coff, accumulate);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small multi-head attention: one thread per (batch, head, query), keys/values read straight
+// from L2 (lanes of one (batch, head) share the same K/V addresses -> broadcast).
+// Used for the 8-latent cross/self attention (crossattentionlayer.py:37-56, encoder.py:156-172,
+// attention.py:9-68) and the decoder's 1-query x 8-key attention (decoder.py:62-109).
+// Element (b, t, h, e) of q lives at q + b*bs + t*ts + h*D + e (same for k, v, out).
+template <int D>
+__global__ __launch_bounds__(256) void attention_small_kernel(const float* __restrict__ q, long q_bs, long q_ts,
+                                                              const float* __restrict__ k, long k_bs, long k_ts,
+                                                              const float* __restrict__ v, long v_bs, long v_ts,
+                                                              float* __restrict__ out, long o_bs, long o_ts, int B,
+                                                              int heads, int Nq, int Nk, float scale) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * heads * Nq) return;
+    const int iq = idx % Nq;
+    const int h = (idx / Nq) % heads;
+    const int b = idx / ((long)Nq * heads);
+    float qr[D], acc[D];
+    const float* qp = q + b * q_bs + iq * q_ts + h * D;
+#pragma unroll
+    for (int e = 0; e < D; e += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(qp + e);
+        qr[e] = t.x; qr[e + 1] = t.y; qr[e + 2] = t.z; qr[e + 3] = t.w;
+    }
+    const float* kb = k + b * k_bs + h * D;
+    const float* vb = v + b * v_bs + h * D;
+    float mx = -INFINITY;
+    for (int j = 0; j < Nk; ++j) {
+        const float* kp = kb + j * k_ts;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < D; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(kp + e);
+            s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
+        }
+        mx = fmaxf(mx, s * scale);
+    }
+#pragma unroll
+    for (int e = 0; e < D; ++e) acc[e] = 0.f;
+    float sum = 0.f;
+    for (int j = 0; j < Nk; ++j) {
+        const float* kp = kb + j * k_ts;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < D; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(kp + e);
+            s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
+        }
+        const float p = expf(s * scale - mx);
+        sum += p;
+        const float* vp = vb + j * v_ts;
+#pragma unroll
+        for (int e = 0; e < D; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(vp + e);
+            acc[e] = fmaf(p, t.x, acc[e]); acc[e + 1] = fmaf(p, t.y, acc[e + 1]);
+            acc[e + 2] = fmaf(p, t.z, acc[e + 2]); acc[e + 3] = fmaf(p, t.w, acc[e + 3]);
+        }
+    }
+    const float inv = 1.0f / sum;
+    float* op = out + b * o_bs + iq * o_ts + h * D;
+#pragma unroll
+    for (int e = 0; e < D; e += 4)
+        *reinterpret_cast<float4*>(op + e) = make_float4(acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv);
+}
+
+extern "C" int st_attention_small(const float* q, int64_t q_bs, int64_t q_ts, const float* k, int64_t k_bs, int64_t k_ts,
+                                  const float* v, int64_t v_bs, int64_t v_ts, float* out, int64_t o_bs, int64_t o_ts,
+                                  int32_t B, int32_t heads, int32_t Nq, int32_t Nk, int32_t D, float scale, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return ST_EINVAL;
+    const long total = (long)B * heads * Nq;
+    dim3 grid((total + 255) / 256), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_AS(DD) hipLaunchKernelGGL(attention_small_kernel<DD>, grid, block, 0, s, q, q_bs, q_ts, k, k_bs, k_ts, v, \
+                                         v_bs, v_ts, out, o_bs, o_ts, B, heads, Nq, Nk, scale)
+    if (D == 8) LAUNCH_AS(8); else if (D == 16) LAUNCH_AS(16); else if (D == 32) LAUNCH_AS(32); else return ST_EINVAL;
+#undef LAUNCH_AS
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Global sub-sampled attention (GSA, twins.py:336-392,633-680): many queries against <= 256
+// pooled keys.  The (batch, head) K/V slab is staged once in LDS and every thread owns one query
+// (online softmax); LDS reads are wave-uniform broadcasts.
+template <int D>
+__global__ __launch_bounds__(256) void attention_kvlds_kernel(const float* __restrict__ q, long q_bs, long q_ts,
+                                                              const float* __restrict__ k, long k_bs, long k_ts,
+                                                              const float* __restrict__ v, long v_bs, long v_ts,
+                                                              float* __restrict__ out, long o_bs, long o_ts, int Nq, int Nk,
+                                                              float scale) {
+    extern __shared__ __attribute__((aligned(16))) float kv[];   // [Nk][D] K then [Nk][D] V
+    const int h = blockIdx.y, b = blockIdx.z;
+    float* Ks = kv;
+    float* Vs = kv + (size_t)Nk * D;
+    for (int i = threadIdx.x; i < Nk * (D / 4); i += 256) {
+        const int j = i / (D / 4), e = (i % (D / 4)) * 4;
+        *reinterpret_cast<float4*>(Ks + j * D + e) = *reinterpret_cast<const float4*>(k + b * k_bs + j * k_ts + h * D + e);
+        *reinterpret_cast<float4*>(Vs + j * D + e) = *reinterpret_cast<const float4*>(v + b * v_bs + j * v_ts + h * D + e);
+    }
+    __syncthreads();
+    const int iq = blockIdx.x * 256 + threadIdx.x;
+    if (iq >= Nq) return;
+    float qr[D], acc[D];
+    const float* qp = q + b * q_bs + iq * q_ts + h * D;
+#pragma unroll
+    for (int e = 0; e < D; e += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(qp + e);
+        qr[e] = t.x * scale; qr[e + 1] = t.y * scale; qr[e + 2] = t.z * scale; qr[e + 3] = t.w * scale;
+    }
+#pragma unroll
+    for (int e = 0; e < D; ++e) acc[e] = 0.f;
+    float mx = -INFINITY, sum = 0.f;
+    for (int j = 0; j < Nk; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < D; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(Ks + j * D + e);
+            s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
+        }
+        const float nm = fmaxf(mx, s);
+        const float corr = expf(mx - nm), p = expf(s - nm);
+        mx = nm;
+        sum = sum * corr + p;
+#pragma unroll
+        for (int e = 0; e < D; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(Vs + j * D + e);
+            acc[e] = fmaf(p, t.x, acc[e] * corr); acc[e + 1] = fmaf(p, t.y, acc[e + 1] * corr);
+            acc[e + 2] = fmaf(p, t.z, acc[e + 2] * corr); acc[e + 3] = fmaf(p, t.w, acc[e + 3] * corr);
+        }
+    }
+    const float inv = 1.0f / sum;
+    float* op = out + b * o_bs + iq * o_ts + h * D;
+#pragma unroll
+    for (int e = 0; e < D; e += 4)
+        *reinterpret_cast<float4*>(op + e) = make_float4(acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv);
+}
+
+extern "C" int st_attention_kvlds(const float* q, int64_t q_bs, int64_t q_ts, const float* k, int64_t k_bs, int64_t k_ts,
+                                  const float* v, int64_t v_bs, int64_t v_ts, float* out, int64_t o_bs, int64_t o_ts,
+                                  int32_t B, int32_t heads, int32_t Nq, int32_t Nk, int32_t D, float scale, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return ST_EINVAL;
+    const size_t lds = (size_t)2 * Nk * D * sizeof(float);
+    if (lds > 160 * 1024) return ST_EINVAL;
+    dim3 grid((Nq + 255) / 256, heads, B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_AK(DD)                                                                                                   \
+    do {                                                                                                                \
+        auto kern = attention_kvlds_kernel<DD>;                                                                         \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, q, q_bs, q_ts, k, k_bs, k_ts, v, v_bs, v_ts, out, o_bs, o_ts, Nq, \
+                           Nk, scale);                                                                                  \
+    } while (0)
+    if (D == 16) LAUNCH_AK(16); else if (D == 32) LAUNCH_AK(32); else return ST_EINVAL;
+#undef LAUNCH_AK
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Locally-grouped (7x7 window) attention, LSA (twins.py:253-304,587-631).  Token (b, y, x) of
+// q/k/v lives at base + b*bs + (y*W + x)*ts + h*D.  The grid is zero-padded to a multiple of ws
+// *before* the q/k/v projections in the reference, so a padded token's q/k/v is a constant per
+// window position: tables qpad/kpad/vpad [ws*ws, heads*D].  One wave per (window, head).
+template <int D>
+__global__ __launch_bounds__(256) void window_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, long bs, long ts,
+                                                               const float* __restrict__ qpad, const float* __restrict__ kpad,
+                                                               const float* __restrict__ vpad, float* __restrict__ out,
+                                                               long o_bs, long o_ts, int H, int W, int heads, int ws,
+                                                               float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nww = (W + ws - 1) / ws;
+    const int win = blockIdx.x, b = blockIdx.z;
+    const int h = blockIdx.y * 4 + wave;
+    if (h >= heads) return;                                    // whole wave exits together
+    const int wy = win / nww, wx = win % nww;
+    const int T = ws * ws, C = heads * D;
+    float* Ks = sm + (size_t)wave * 2 * T * D;
+    float* Vs = Ks + (size_t)T * D;
+    const int ty = lane / ws, tx = lane % ws;
+    const int y = wy * ws + ty, x = wx * ws + tx;
+    const bool tok = lane < T;
+    const bool inb = tok && y < H && x < W;
+    float qr[D];
+    if (tok) {
+        const float* qp = inb ? q + b * bs + ((long)y * W + x) * ts + h * D : qpad + (size_t)lane * C + h * D;
+        const float* kp = inb ? k + b * bs + ((long)y * W + x) * ts + h * D : kpad + (size_t)lane * C + h * D;
+        const float* vp = inb ? v + b * bs + ((long)y * W + x) * ts + h * D : vpad + (size_t)lane * C + h * D;
+#pragma unroll
+        for (int e = 0; e < D; e += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + e);
+            qr[e] = a.x; qr[e + 1] = a.y; qr[e + 2] = a.z; qr[e + 3] = a.w;
+            *reinterpret_cast<float4*>(Ks + lane * D + e) = *reinterpret_cast<const float4*>(kp + e);
+            *reinterpret_cast<float4*>(Vs + lane * D + e) = *reinterpret_cast<const float4*>(vp + e);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes visible to its own lanes
+    if (!inb) return;
+    float mx = -INFINITY;
+    for (int j = 0; j < T; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < D; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(Ks + j * D + e);
+            s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
+        }
+        mx = fmaxf(mx, s * scale);
+    }
+    float acc[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) acc[e] = 0.f;
+    float sum = 0.f;
+    for (int j = 0; j < T; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < D; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(Ks + j * D + e);
+            s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
+        }
+        const float p = expf(s * scale - mx);
+        sum += p;
+#pragma unroll
+        for (int e = 0; e < D; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(Vs + j * D + e);
+            acc[e] = fmaf(p, t.x, acc[e]); acc[e + 1] = fmaf(p, t.y, acc[e + 1]);
+            acc[e + 2] = fmaf(p, t.z, acc[e + 2]); acc[e + 3] = fmaf(p, t.w, acc[e + 3]);
+        }
+    }
+    const float inv = 1.0f / sum;
+    float* op = out + b * o_bs + ((long)y * W + x) * o_ts + h * D;
+#pragma unroll
+    for (int e = 0; e < D; e += 4)
+        *reinterpret_cast<float4*>(op + e) = make_float4(acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv);
+}
+
+extern "C" int st_window_attention(const float* q, const float* k, const float* v, int64_t bs, int64_t ts, const float* qpad,
+                                   const float* kpad, const float* vpad, float* out, int64_t o_bs, int64_t o_ts, int32_t B,
+                                   int32_t H, int32_t W, int32_t heads, int32_t D, int32_t ws, float scale, void* stream) {
+    if (!q || !k || !v || !qpad || !kpad || !vpad || !out || ws * ws > 64 || ws <= 0) return ST_EINVAL;
+    const int nwh = (H + ws - 1) / ws, nww = (W + ws - 1) / ws;
+    dim3 grid(nwh * nww, (heads + 3) / 4, B), block(256);
+    const size_t lds = (size_t)4 * 2 * ws * ws * D * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_WA(DD) hipLaunchKernelGGL(window_attention_kernel<DD>, grid, block, lds, s, q, k, v, bs, ts, qpad, kpad, vpad, \
+                                         out, o_bs, o_ts, H, W, heads, ws, scale)
+    if (D == 16) LAUNCH_WA(16); else if (D == 32) LAUNCH_WA(32); else return ST_EINVAL;
+#undef LAUNCH_WA
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CCL soft-argmax (network.py:147-199).  G = n1 . n2^T is the plain all-pairs product of the
+// L2-normalised features ([B, P, P], P = h*w); the reference's "3x3 patches of n2 as conv filters
+// over n1" is vol[p, q] = sum over the 9 offsets d of G[p+d, q+d] (both in bounds).  Softmax over
+// q with temperature 10, then the expected displacement.  out [B, P, ldo] = (flow_w, flow_h, 0..).
+__global__ __launch_bounds__(256) void ccl_softargmax_kernel(const float* __restrict__ G, float* __restrict__ out, int ldo,
+                                                             int h, int w) {
+    __shared__ float red[12];
+    const int P = h * w, p = blockIdx.x, b = blockIdx.y;
+    const int py = p / w, px = p % w;
+    const float* Gb = G + (size_t)b * P * P;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    float vol[4];                                   // P <= 1024
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = t + 256 * i;
+        float s = -INFINITY;
+        if (q < P) {
+            const int qy = q / w, qx = q % w;
+            s = 0.f;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int ay = py + dy, ax = px + dx, by = qy + dy, bx = qx + dx;
+                    if (ay >= 0 && ay < h && ax >= 0 && ax < w && by >= 0 && by < h && bx >= 0 && bx < w)
+                        s += Gb[(size_t)(ay * w + ax) * P + by * w + bx];
+                }
+            s *= 10.0f;
+        }
+        vol[i] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f, fh = 0.f, fw = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = t + 256 * i;
+        if (q < P) {
+            const float e = expf(vol[i] - mx);
+            sum += e;
+            fh += e * (float)(q / w - py);
+            fw += e * (float)(q % w - px);
+        }
+    }
+    sum = wave_sum(sum); fh = wave_sum(fh); fw = wave_sum(fw);
+    if (lane == 0) { red[4 + wv] = sum; red[8 + wv] = fh; }
+    __syncthreads();
+    const float tsum = (red[4] + red[5]) + (red[6] + red[7]);
+    const float tfh = (red[8] + red[9]) + (red[10] + red[11]);
+    __syncthreads();
+    if (lane == 0) red[wv] = fw;
+    __syncthreads();
+    if (t == 0) {
+        const float tfw = (red[0] + red[1]) + (red[2] + red[3]);
+        float* o = out + ((size_t)b * P + p) * ldo;
+        o[0] = tfw / tsum; o[1] = tfh / tsum;
+        for (int c = 2; c < ldo; ++c) o[c] = 0.f;
+    }
+}
+
+extern "C" int st_ccl_softargmax(const float* G, float* out, int32_t ldo, int32_t B, int32_t h, int32_t w, void* stream) {
+    if (!G || !out || h * w > 1024 || ldo < 2) return ST_EINVAL;
+    hipLaunchKernelGGL(ccl_softargmax_kernel, dim3(h * w, B), dim3(256), 0, (hipStream_t)stream, G, out, ldo, h, w);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// strided 2-D copy (channel-slice concatenation)
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows, int cols) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    const int c = idx % cols;
+    const size_t r = idx / cols;
+    dst[r * ldd + c] = src[r * lds_ + c];
+}
+
+extern "C" int st_copy2d(const float* src, int32_t lds_, float* dst, int32_t ldd, int32_t rows, int32_t cols, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0) return ST_EINVAL;
+    const size_t total = (size_t)rows * cols;
+    hipLaunchKernelGGL(copy2d_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, lds_, dst, ldd, rows,
+                       cols);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW image -> channels-last rows [B*H*W, ldo] with the per-branch input scaling
+// (flowHomoAdpater.py:55-56  x/127.5 - 1 ;  transformer.py:53-54  2*(x/255) - 1); pad channels = 0.
+__global__ void prep_image_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W, int ldo,
+                                  float mul, float div, float sub) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t hw = (size_t)H * W;
+    if (idx >= (size_t)B * hw) return;
+    const size_t b = idx / hw, r = idx % hw;
+    for (int c = 0; c < ldo; ++c) {
+        float v = 0.f;
+        if (c < C) v = mul * (src[(b * C + c) * hw + r] / div) - sub;
+        dst[idx * ldo + c] = v;
+    }
+}
+
+extern "C" int st_prep_image(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t ldo,
+                             float mul, float div, float sub, void* stream) {
+    if (!src || !dst || ldo < C) return ST_EINVAL;
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(prep_image_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, B, C, H, W,
+                       ldo, mul, div, sub);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

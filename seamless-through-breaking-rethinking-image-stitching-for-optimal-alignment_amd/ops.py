@@ -1,0 +1,270 @@
+"""Thin host wrappers over the C-ABI: torch tensors are only device memory here -- every call
+passes raw device pointers + sizes to libstitch_gfx950.so on torch's current HIP stream."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import GemmDesc, check, lib
+
+ACT = dict(none=0, relu=1, gelu=2, sigmoid=3, tanh=4)
+EPI = dict(store=0, add=1, mul=2, gru=3, axpy=4)
+
+assert lib.st_abi_gemm_desc_size() == C.sizeof(GemmDesc), "st_gemm_desc ABI mismatch between header and binding"
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "device tensor expected (no CPU fallback)"
+    return C.c_void_p(t.data_ptr())
+
+
+def _ld(t):
+    """row stride of a 2-D row-major view (last dim contiguous)."""
+    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride())
+    return t.stride(0)
+
+
+def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
+              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, M=None, tile=0):
+    """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
+
+    x: 2-D view [rows, Cin] of a channels-last activation; geom=(B,H,W,kh,kw,sh,sw,ph,pw) or None (1x1).
+    w: [N, kh*kw*Cin] view.  out/aux*: 2-D views (column slices of wider buffers are fine)."""
+    d = GemmDesc()
+    Cin = x.shape[1]
+    if geom is None:
+        rows = x.shape[0] if M is None else M
+        B, H, W, kh, kw, sh, sw, ph, pw = 1, 1, rows, 1, 1, 1, 1, 0, 0
+        Ho, Wo = 1, rows
+    else:
+        B, H, W, kh, kw, sh, sw, ph, pw = geom
+        Ho = (H + 2 * ph - kh) // sh + 1
+        Wo = (W + 2 * pw - kw) // sw + 1
+    d.a, d.w, d.c = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.aux0 = aux0.data_ptr() if aux0 is not None else None
+    d.aux1 = aux1.data_ptr() if aux1 is not None else None
+    d.aux2 = aux2.data_ptr() if aux2 is not None else None
+    d.scale_ptr = scale_ptr.data_ptr() if scale_ptr is not None else None
+    d.M, d.N, d.K = B * Ho * Wo, w.shape[0], kh * kw * Cin
+    assert w.shape[1] == d.K, (tuple(w.shape), d.K)
+    d.H, d.W, d.Cin, d.ldx = H, W, Cin, _ld(x)
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.Ho, d.Wo = kh, kw, sh, sw, ph, pw, Ho, Wo
+    d.ldw, d.ldc = _ld(w), _ld(out)
+    d.ld_aux0 = _ld(aux0) if aux0 is not None else 0
+    d.ld_aux1 = _ld(aux1) if aux1 is not None else 0
+    d.ld_aux2 = _ld(aux2) if aux2 is not None else 0
+    d.aux0_row_div, d.aux0_row_mod = row_div, row_mod
+    d.act, d.epi, d.alpha = ACT[act], EPI[epi], alpha
+    d.batch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_c = batch, bsa, bsw, bsc
+    d.tile_cfg = tile
+    check(lib.st_conv_gemm(C.byref(d), _stream()), "st_conv_gemm")
+    return out
+
+
+def corr_volume(f1, f2, out):
+    B, N1, Cc = f1.shape
+    N2 = f2.shape[1]
+    check(lib.st_corr_volume(_p(f1), _p(f2), _p(out), B, N1, N2, Cc, _stream()), "st_corr_volume")
+    return out
+
+
+def layernorm(x, w, b, out, eps):
+    check(lib.st_layernorm(_p(x), _ld(x), _p(w), _p(b), _p(out), _ld(out), x.shape[0], x.shape[1], eps, _stream()),
+          "st_layernorm")
+    return out
+
+
+def softmax_rows(x):
+    check(lib.st_softmax_rows(_p(x), _ld(x), x.shape[0], x.shape[1], _stream()), "st_softmax_rows")
+    return x
+
+
+def l2norm_rows(x, out):
+    check(lib.st_l2norm_rows(_p(x), _p(out), x.shape[0], x.shape[1], _stream()), "st_l2norm_rows")
+    return out
+
+
+def maxpool(x, out, B, H, W, Cc, k, s, p):
+    check(lib.st_maxpool_nhwc(_p(x), _p(out), B, H, W, Cc, k, s, p, _stream()), "st_maxpool_nhwc")
+    return out
+
+
+def dwconv3x3_residual(x, w9c, bias, out, B, H, W, Cc):
+    check(lib.st_dwconv3x3_residual(_p(x), _p(w9c), _p(bias), _p(out), B, H, W, Cc, _stream()), "st_dwconv3x3_residual")
+    return out
+
+
+def sine_pe(out, dim, *, coords=None, Wg=0, ws=0, cscale=1.0, coff=0.0, accumulate=False):
+    check(lib.st_sine_pe(_p(out), _ld(out), out.shape[0], dim, _p(coords), _ld(coords) if coords is not None else 0,
+                         Wg, ws, cscale, coff, int(accumulate), _stream()), "st_sine_pe")
+    return out
+
+
+def attention_small(q, qs, k, ks, v, vs, out, os_, B, heads, Nq, Nk, D, scale):
+    check(lib.st_attention_small(_p(q), qs[0], qs[1], _p(k), ks[0], ks[1], _p(v), vs[0], vs[1], _p(out), os_[0], os_[1],
+                                 B, heads, Nq, Nk, D, scale, _stream()), "st_attention_small")
+    return out
+
+
+def attention_kvlds(q, qs, k, ks, v, vs, out, os_, B, heads, Nq, Nk, D, scale):
+    check(lib.st_attention_kvlds(_p(q), qs[0], qs[1], _p(k), ks[0], ks[1], _p(v), vs[0], vs[1], _p(out), os_[0], os_[1],
+                                 B, heads, Nq, Nk, D, scale, _stream()), "st_attention_kvlds")
+    return out
+
+
+def window_attention(q, k, v, bs, ts, qpad, kpad, vpad, out, o_bs, o_ts, B, H, W, heads, D, ws, scale):
+    check(lib.st_window_attention(_p(q), _p(k), _p(v), bs, ts, _p(qpad), _p(kpad), _p(vpad), _p(out), o_bs, o_ts, B, H, W,
+                                  heads, D, ws, scale, _stream()), "st_window_attention")
+    return out
+
+
+def ccl_softargmax(G, out, B, h, w):
+    check(lib.st_ccl_softargmax(_p(G), _p(out), _ld(out), B, h, w, _stream()), "st_ccl_softargmax")
+    return out
+
+
+def copy2d(src, dst):
+    check(lib.st_copy2d(_p(src), _ld(src), _p(dst), _ld(dst), src.shape[0], src.shape[1], _stream()), "st_copy2d")
+    return dst
+
+
+def prep_image(src, dst, ldo, mul, div, sub):
+    B, Cc, H, W = src.shape
+    check(lib.st_prep_image(_p(src), _p(dst), B, Cc, H, W, ldo, mul, div, sub, _stream()), "st_prep_image")
+    return dst
+
+
+def coords_grid(out, B, H, W):
+    check(lib.st_coords_grid(_p(out), B, H, W, _stream()), "st_coords_grid")
+    return out
+
+
+def flow_from_coords(coords1, flow4, dst2, B, H, W):
+    check(lib.st_flow_from_coords(_p(coords1), _p(flow4), _ld(flow4) if flow4 is not None else 0, _p(dst2),
+                                  _ld(dst2) if dst2 is not None else 0, B, H, W, _stream()), "st_flow_from_coords")
+
+
+def cost_lookup(maps, coords, out, Nq, H2, W2, r=4):
+    check(lib.st_cost_lookup(_p(maps), _p(coords), _p(out), _ld(out), Nq, H2, W2, r, _stream()), "st_cost_lookup")
+    return out
+
+
+def convex_upsample(coords1, mask, out, B, H, W):
+    check(lib.st_convex_upsample(_p(coords1), _p(mask), _ld(mask), _p(out), B, H, W, _stream()), "st_convex_upsample")
+    return out
+
+
+# ---- geometric stage (NCHW) ------------------------------------------------------------------
+def dlt4(src4x2, motion, H_out, B, mscale_x=1.0, mscale_y=1.0, div=1.0):
+    check(lib.st_dlt4(_p(src4x2), _p(motion), _p(H_out), B, mscale_x, mscale_y, div, _stream()), "st_dlt4")
+    return H_out
+
+
+def mat3_sandwich(L, X, R, out, invert=False):
+    check(lib.st_mat3_sandwich(_p(L), _p(X), _p(R), _p(out), X.shape[0], int(invert), _stream()), "st_mat3_sandwich")
+    return out
+
+
+def homo_warp(U, theta, out_hw, n_ones=0, want_idx=False, want_out=True):
+    """U [B,C,H,W] (or None with C=0) -> out [B,C+n_ones,oh,ow] (+ idx [B,oh,ow,4] int32)."""
+    B = theta.shape[0]
+    if U is not None:
+        _, Cc, H, W = U.shape
+    else:
+        raise ValueError("U required (pass n_ones for the implicit mask channels)")
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((B, Cc + n_ones, oh, ow), device=theta.device, dtype=torch.float32) if want_out else None
+    idx = torch.empty((B, oh, ow, 4), device=theta.device, dtype=torch.int32) if want_idx else None
+    check(lib.st_homo_warp(_p(U), _p(theta), _p(out), _p(idx), B, Cc, n_ones, H, W, oh, ow, _stream()), "st_homo_warp")
+    return (out, idx) if want_idx else out
+
+
+def mesh_bounds(H, out4, width, height, gw=511, gh=511):
+    check(lib.st_mesh_bounds(_p(H), _p(out4), H.shape[0], float(width), float(height), gw, gh, _stream()), "st_mesh_bounds")
+    return out4
+
+
+def flow_warp(x, flow, mul=None):
+    B, Cc, H, W = x.shape
+    out = torch.empty_like(x)
+    check(lib.st_flow_warp(_p(x), _p(flow), _p(mul), _p(out), B, Cc, H, W, _stream()), "st_flow_warp")
+    return out
+
+
+def resize_bilinear(x, oh, ow, align_corners, div=None):
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, oh, ow), device=x.device, dtype=torch.float32)
+    d0, d1, nd = (div[0], div[1], 2) if div is not None else (1.0, 1.0, 0)
+    check(lib.st_resize_bilinear(_p(x), _p(out), B * Cc, H, W, oh, ow, int(align_corners), d0, d1, nd, _stream()),
+          "st_resize_bilinear")
+    return out
+
+
+def range_map(flow):
+    B, _, H, W = flow.shape
+    scratch = torch.empty((B * H * W,), device=flow.device, dtype=torch.int64)
+    out = torch.empty((B, 1, H, W), device=flow.device, dtype=torch.float32)
+    check(lib.st_range_map(_p(flow), _p(scratch), _p(out), B, H, W, _stream()), "st_range_map")
+    return out
+
+
+def occlusion_from_range(rng, threshold):
+    out = torch.empty_like(rng)
+    check(lib.st_occlusion_from_range(_p(rng), _p(out), rng.numel(), int(threshold), _stream()), "st_occlusion_from_range")
+    return out
+
+
+def morph_open(mask, ksz=19):
+    B, Cc, H, W = mask.shape
+    scratch = torch.empty((2 * B * Cc * H * W,), device=mask.device, dtype=torch.uint8)
+    out = torch.empty_like(mask)
+    check(lib.st_morph_open(_p(mask), _p(out), _p(scratch), B * Cc, H, W, ksz, _stream()), "st_morph_open")
+    return out
+
+
+def eval_finish(final6, occ):
+    B, _, H, W = final6.shape
+    overlap = torch.empty((B, H, W), device=final6.device, dtype=torch.float32)
+    check(lib.st_eval_finish(_p(final6), _p(occ), _p(overlap), B, H, W, _stream()), "st_eval_finish")
+    return overlap
+
+
+def blend(homo1, homo2, fin, occ):
+    _, _, h, w = homo1.shape
+    dev = homo1.device
+    o2 = torch.empty((1, 3, h, w), device=dev)
+    m1 = torch.empty((1, 3, h, w), device=dev)
+    m2 = torch.empty((1, 3, h, w), device=dev)
+    bl = torch.empty((1, 3, h, w), device=dev, dtype=torch.uint8)
+    check(lib.st_blend(_p(homo1), _p(homo2), _p(fin), _p(occ), _p(o2), _p(m1), _p(m2), _p(bl), h, w, _stream()), "st_blend")
+    return o2, m1, m2, bl
+
+
+def mean_threshold(x, thr):
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+    check(lib.st_mean_threshold(_p(x), _p(out), B, Cc, H, W, thr, _stream()), "st_mean_threshold")
+    return out
+
+
+def tps_transform(U, source, target, out_hw, want_idx=False):
+    """UDIS2 TPS transformer: U [B,C,H,W], source/target [B,N,2] in [-1,1] -> [B,C,oh,ow] (+T, idx)."""
+    B, Cc, H, W = U.shape
+    N = source.shape[1]
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    dev = U.device
+    work = torch.empty((B * (N + 3) * (N + 5),), device=dev, dtype=torch.float64)
+    T = torch.empty((B, 2, N + 3), device=dev, dtype=torch.float32)
+    out = torch.empty((B, Cc, oh, ow), device=dev, dtype=torch.float32)
+    idx = torch.empty((B, oh, ow, 4), device=dev, dtype=torch.int32) if want_idx else None
+    check(lib.st_tps_solve_grid(_p(U), _p(source.contiguous()), _p(target.contiguous()), _p(work), _p(T), _p(out), _p(idx),
+                                B, Cc, H, W, N, oh, ow, _stream()), "st_tps_solve_grid")
+    return (out, T, idx) if want_idx else (out, T)

@@ -1,0 +1,382 @@
+"""Per-kernel parity on the GPU: every HIP entry point (called through the C-ABI) against the CPU
+oracle on the same seeded inputs.  Tolerances: integer / index / mask data bit-exact; fp32
+contractions 1e-4 relative (different accumulation order); resampling < 1e-3 (north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cgeom, geom, nets  # noqa: E402
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import stitch_amd
+    assert torch.cuda.is_available()
+    return stitch_amd.ops
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def nhwc(x):
+    """NCHW cpu -> [B*H*W, C] cuda rows"""
+    B, C, H, W = x.shape
+    return dev(x.permute(0, 2, 3, 1).reshape(B * H * W, C))
+
+
+def from_rows(y, B, H, W):
+    return y.cpu().reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def pack_conv_w(w, cpad=None):
+    Co, Ci, kh, kw = w.shape
+    cpad = Ci if cpad is None else cpad
+    wp = torch.zeros(Co, kh, kw, cpad)
+    wp[..., :Ci] = w.permute(0, 2, 3, 1)
+    return dev(wp.reshape(Co, kh * kw * cpad))
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 128, 256), (300, 70, 36), (129, 2, 1152), (4096, 4096, 256), (5, 4096, 4096),
+                                   (1000, 257, 100)])
+def test_gemm_linear(ops, M, N, K):
+    a, w, b = torch.randn(M, K, generator=g(1)), torch.randn(N, K, generator=g(2)) / K ** 0.5, torch.randn(N, generator=g(3))
+    ref = F.linear(a.double(), w.double(), b.double())
+    out = torch.empty(M, N, device="cuda")
+    ops.conv_gemm(dev(a), dev(w), out, bias=dev(b))
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_gemm_tiles_and_epilogues(ops, tile):
+    M, N, K = 777, 130, 200
+    a, w = torch.randn(M, K, generator=g(4)), torch.randn(N, K, generator=g(5)) / K ** 0.5
+    bias, x0 = torch.randn(N, generator=g(6)), torch.randn(M // 7 + 1, N, generator=g(7))
+    z, h = torch.rand(M, N, generator=g(8)), torch.randn(M, N, generator=g(9))
+    base = F.linear(a, w) * 0.5 + bias + x0[torch.arange(M) // 7]
+    want = (1 - z) * h + z * torch.tanh(base)
+    out = torch.empty(M, N + 6, device="cuda")
+    ops.conv_gemm(dev(a), dev(w), out[:, 3:3 + N], bias=dev(bias), alpha=0.5, aux0=dev(x0), row_div=7, act="tanh",
+                  epi="gru", aux1=dev(z), aux2=dev(h), tile=tile)
+    assert (out[:, 3:3 + N].cpu() - want).abs().max() < 2e-5
+    gam = torch.tensor([0.37])
+    ops.conv_gemm(dev(a), dev(w), out[:, 3:3 + N], act="gelu", epi="axpy", aux1=dev(h), scale_ptr=dev(gam), tile=tile)
+    assert (out[:, 3:3 + N].cpu() - (h + 0.37 * F.gelu(F.linear(a, w)))).abs().max() < 2e-5
+    ops.conv_gemm(dev(a), dev(w), out[:, 3:3 + N], act="sigmoid", epi="mul", aux1=dev(h), aux0=dev(x0[:5]), row_mod=5, tile=tile)
+    want = torch.sigmoid(F.linear(a, w) + x0[:5][torch.arange(M) % 5]) * h
+    assert (out[:, 3:3 + N].cpu() - want).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, C=8, H=17, W=23, Co=24, kh=3, kw=3, s=1, p=1),
+    dict(B=1, C=512, H=12, W=16, Co=128, kh=1, kw=5, s=1, p=(0, 2)),
+    dict(B=1, C=512, H=12, W=16, Co=128, kh=5, kw=1, s=1, p=(2, 0)),
+    dict(B=3, C=1, H=64, W=64, Co=16, kh=6, kw=6, s=2, p=2),          # scalar-gather path (PatchEmbed conv1)
+    dict(B=2, C=16, H=32, W=32, Co=32, kh=6, kw=6, s=2, p=2),
+    dict(B=1, C=3, H=64, W=96, Co=64, kh=7, kw=7, s=2, p=3, cpad=4),   # ResNet conv1, channels padded to 4
+    dict(B=1, C=3, H=64, W=96, Co=128, kh=4, kw=4, s=4, p=0, cpad=4),  # Twins patch embed
+    dict(B=1, C=128, H=12, W=16, Co=128, kh=4, kw=4, s=4, p=0),        # sr conv
+    dict(B=2, C=64, H=20, W=20, Co=256, kh=1, kw=1, s=2, p=0),         # strided 1x1 (ResNet downsample)
+])
+def test_conv_nhwc(ops, cfg):
+    B, C, H, W, Co, kh, kw, s = (cfg[k] for k in ("B", "C", "H", "W", "Co", "kh", "kw", "s"))
+    p = cfg["p"] if isinstance(cfg["p"], tuple) else (cfg["p"], cfg["p"])
+    cpad = cfg.get("cpad", C)
+    x = torch.randn(B, C, H, W, generator=g(10))
+    w = torch.randn(Co, C, kh, kw, generator=g(11)) / (C * kh * kw) ** 0.5
+    b = torch.randn(Co, generator=g(12))
+    ref = F.relu(F.conv2d(x, w, b, stride=s, padding=p))
+    xr = torch.zeros(B * H * W, cpad)
+    xr[:, :C] = x.permute(0, 2, 3, 1).reshape(-1, C)
+    Ho, Wo = ref.shape[2:]
+    out = torch.empty(B * Ho * Wo, Co, device="cuda")
+    ops.conv_gemm(dev(xr), pack_conv_w(w, cpad), out, geom=(B, H, W, kh, kw, s, s, p[0], p[1]), bias=dev(b), act="relu")
+    assert (from_rows(out, B, Ho, Wo) - ref).abs().max() < 2e-5
+
+
+def test_corr_volume(ops):
+    f1, f2 = torch.randn(2, 256, 16, 16, generator=g(13)), torch.randn(2, 256, 16, 16, generator=g(14))
+    ref = nets.corr_volume(f1, f2)
+    a = dev(f1.reshape(2, 256, -1).transpose(1, 2))
+    b = dev(f2.reshape(2, 256, -1).transpose(1, 2))
+    out = torch.empty(2, 256, 256, device="cuda")
+    ops.corr_volume(a, b, out)
+    assert (out.cpu() - ref).abs().max() < 1e-4
+
+
+def test_rowwise_ops(ops):
+    x = torch.randn(1000, 192, generator=g(15)) * 3 + 1
+    w, b = torch.randn(192, generator=g(16)), torch.randn(192, generator=g(17))
+    out = torch.empty(1000, 200, device="cuda")
+    for eps in (1e-5, 1e-6):
+        ops.layernorm(dev(x), dev(w), dev(b), out[:, :192], eps)
+        assert (out[:, :192].cpu() - F.layer_norm(x, (192,), w, b, eps)).abs().max() < 2e-5
+    s = torch.randn(300, 4096, generator=g(18)) * 4
+    sd = dev(s)
+    ops.softmax_rows(sd)
+    assert (sd.cpu() - torch.softmax(s, -1)).abs().max() < 5e-6
+    s2 = torch.randn(7, 100, generator=g(19))
+    sd2 = dev(s2)
+    ops.softmax_rows(sd2)
+    assert (sd2.cpu() - torch.softmax(s2, -1)).abs().max() < 5e-6
+    f = torch.randn(500, 1024, generator=g(20))
+    o = torch.empty(500, 1024, device="cuda")
+    ops.l2norm_rows(dev(f), o)
+    assert (o.cpu() - F.normalize(f, p=2, dim=1)).abs().max() < 1e-6
+
+
+def test_maxpool_and_peg(ops):
+    x = torch.randn(2, 32, 19, 23, generator=g(21))
+    for k, s, p in ((3, 2, 1), (2, 2, 0)):
+        ref = F.max_pool2d(x, k, s, p)
+        out = torch.empty(2 * ref.shape[2] * ref.shape[3], 32, device="cuda")
+        ops.maxpool(nhwc(x), out, 2, 19, 23, 32, k, s, p)
+        assert torch.equal(from_rows(out, 2, ref.shape[2], ref.shape[3]), ref)
+    w, b = torch.randn(32, 1, 3, 3, generator=g(22)), torch.randn(32, generator=g(23))
+    ref = F.conv2d(x, w, b, padding=1, groups=32) + x
+    out = torch.empty(2 * 19 * 23, 32, device="cuda")
+    ops.dwconv3x3_residual(nhwc(x), dev(w.reshape(32, 9).t()), dev(b), out, 2, 19, 23, 32)
+    assert (from_rows(out, 2, 19, 23) - ref).abs().max() < 1e-5
+
+
+def test_sine_pe(ops):
+    c = torch.rand(77, 2, generator=g(24)) * 60
+    out = torch.zeros(77, 70, device="cuda")
+    ops.sine_pe(out[:, :64], 64, coords=dev(c))
+    assert (out[:, :64].cpu() - nets.sine_pe(c, 64)).abs().max() < 2e-5
+    grid = nets.coords_grid(1, 5, 9).view(1, 2, -1).permute(0, 2, 1)[0]
+    o2 = torch.ones(45, 192, device="cuda")
+    ops.sine_pe(o2, 192, Wg=9, cscale=8.0, coff=4.0, accumulate=True)
+    assert (o2.cpu() - (1 + nets.sine_pe(grid * 8 + 4, 192))).abs().max() < 3e-5
+    o3 = torch.empty(14 * 14, 128, device="cuda")
+    ops.sine_pe(o3, 128, Wg=14, ws=7)
+    gx = nets.coords_grid(1, 14, 14).view(1, 2, -1).permute(0, 2, 1)[0] % 7
+    assert (o3.cpu() - nets.sine_pe(gx, 128)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,D,bq", [(50, 8, 8, 64, 16, True), (50, 8, 8, 8, 16, False), (300, 8, 1, 8, 8, False)])
+def test_attention_small(ops, B, heads, Nq, Nk, D, bq):
+    C = heads * D
+    q = torch.randn(1 if bq else B, Nq, C, generator=g(25))
+    k, v = torch.randn(B, Nk, C, generator=g(26)), torch.randn(B, Nk, C, generator=g(27))
+    ref = nets.mha(q, k, v, heads, D ** -0.5)
+    out = torch.empty(B, Nq, C, device="cuda")
+    ops.attention_small(dev(q), (0 if bq else Nq * C, C), dev(k), (Nk * C, C), dev(v), (Nk * C, C), out, (Nq * C, C),
+                        B, heads, Nq, Nk, D, D ** -0.5)
+    assert (out.cpu() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("Nq,Nk,D,heads", [(1000, 256, 32, 4), (4096, 256, 16, 8), (192, 12, 16, 8)])
+def test_attention_kvlds(ops, Nq, Nk, D, heads):
+    C, B = heads * D, 2
+    q, k, v = (torch.randn(B, n, C, generator=g(s)) for n, s in ((Nq, 28), (Nk, 29), (Nk, 30)))
+    ref = nets.mha(q, k, v, heads, D ** -0.5)
+    out = torch.empty(B, Nq, C, device="cuda")
+    ops.attention_kvlds(dev(q), (Nq * C, C), dev(k), (Nk * C, C), dev(v), (Nk * C, C), out, (Nq * C, C), B, heads, Nq, Nk,
+                        D, D ** -0.5)
+    assert (out.cpu() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("H,W,heads,D", [(16, 24, 4, 32), (12, 16, 8, 16), (14, 7, 8, 32)])
+def test_window_attention(ops, H, W, heads, D):
+    """LSA core vs the oracle's padded-window attention (twins.py:587-631) with q/k/v given."""
+    B, C, ws = 2, heads * D, 7
+    q, k, v = (torch.randn(B, H * W, C, generator=g(s)) for s in (31, 32, 33))
+    qpad, kpad, vpad = (torch.randn(49, C, generator=g(s)) for s in (34, 35, 36))
+
+    def windows(t, pad):
+        t = t.view(B, H, W, C)
+        pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+        Hp, Wp = H + pb, W + pr
+        full = pad.view(1, 1, ws, 1, ws, C).expand(B, Hp // ws, ws, Wp // ws, ws, C).reshape(B, Hp, Wp, C).clone()
+        full[:, :H, :W] = t
+        return full.reshape(B, Hp // ws, ws, Wp // ws, ws, C).transpose(2, 3).reshape(-1, 49, C), Hp, Wp
+    qw, Hp, Wp = windows(q, qpad)
+    kw, _, _ = windows(k, kpad)
+    vw, _, _ = windows(v, vpad)
+    o = nets.mha(qw, kw, vw, heads, D ** -0.5)
+    ref = o.reshape(B, Hp // ws, Wp // ws, ws, ws, C).transpose(2, 3).reshape(B, Hp, Wp, C)[:, :H, :W].reshape(B, H * W, C)
+    out = torch.empty(B, H * W, C, device="cuda")
+    ops.window_attention(dev(q), dev(k), dev(v), H * W * C, C, dev(qpad), dev(kpad), dev(vpad), out, H * W * C, C, B, H, W,
+                         heads, D, ws, D ** -0.5)
+    assert (out.cpu() - ref).abs().max() < 2e-5
+
+
+def test_ccl(ops, golden_ops):
+    f1, f2 = T(golden_ops["ccl_f1"]), T(golden_ops["ccl_f2"])
+    B, C, h, w = f1.shape
+    n1, n2 = torch.empty(B * h * w, C, device="cuda"), torch.empty(B * h * w, C, device="cuda")
+    ops.l2norm_rows(nhwc(f1), n1)
+    ops.l2norm_rows(nhwc(f2), n2)
+    G = torch.empty(B, h * w, h * w, device="cuda")
+    ops.corr_volume(n1.view(B, h * w, C), n2.view(B, h * w, C), G)
+    out = torch.empty(B * h * w, 4, device="cuda")
+    ops.ccl_softargmax(G, out, B, h, w)
+    got = from_rows(out, B, h, w)
+    assert (got[:, :2] - T(golden_ops["ccl_out"])).abs().max() < 1e-4
+    assert (got[:, 2:] == 0).all()
+
+
+def test_cost_lookup_and_upsample(ops, golden_ops):
+    gd = golden_ops
+    maps, coords = T(gd["lookup_maps"]), T(gd["lookup_coords"])
+    Nq = maps.shape[0]
+    c = nhwc(coords)
+    out = torch.zeros(Nq, 84, device="cuda")
+    ops.cost_lookup(dev(maps.reshape(Nq, -1)), c, out, Nq, 12, 16)
+    assert (from_rows(out[:, :81], 1, 12, 16) - T(gd["lookup_out"])).abs().max() < 1e-4
+    flow, mask = T(gd["ub_flow"]), T(gd["ub_mask"])
+    c1 = nhwc(flow + nets.coords_grid(1, 12, 16))
+    up = torch.empty(1, 2, 96, 128, device="cuda")
+    ops.convex_upsample(c1, nhwc(mask), up, 1, 12, 16)
+    assert (up.cpu() - T(gd["up_out"])).abs().max() < 1e-4
+    f4 = torch.empty(12 * 16, 4, device="cuda")
+    ops.flow_from_coords(c1, f4, None, 1, 12, 16)
+    assert (from_rows(f4[:, :2], 1, 12, 16) - flow).abs().max() < 1e-5 and (f4[:, 2:] == 0).all()
+    cg = torch.empty(2 * 12 * 16, 2, device="cuda")
+    ops.coords_grid(cg, 2, 12, 16)
+    assert torch.equal(from_rows(cg, 2, 12, 16), nets.coords_grid(2, 12, 16))
+
+
+# ---------------------------------------------------------------- geometric stage
+def test_homo_warp_indices_bit_exact(ops, golden_ops):
+    U, theta = T(golden_ops["homo_U"]), T(golden_ops["homo_theta"])
+    out, idx = ops.homo_warp(dev(U), dev(theta.reshape(2, 9)), (33, 47), want_idx=True)
+    ref_out, ref_idx = cgeom.homo_warp(U.numpy(), theta.numpy(), (33, 47))
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)                      # grid indices bit-exact
+    assert np.array_equal(out.cpu().numpy(), golden_ops["homo_out"])       # == reference output, bit for bit
+    assert np.array_equal(out.cpu().numpy(), ref_out)
+
+
+@pytest.mark.parametrize("hw,ohw", [((512, 512), (512, 512)), ((300, 400), (315, 439)), ((64, 64), (1025, 1026))])
+def test_homo_warp_sizes_and_ones(ops, hw, ohw):
+    gg = g(40)
+    U = torch.rand(1, 3, *hw, generator=gg) * 255
+    theta = (torch.eye(3) + torch.tensor([[0.08, 0.03, 0.05], [-0.02, 0.1, -0.04], [0.02, -0.03, 0.0]])).reshape(1, 9)
+    out, idx = ops.homo_warp(dev(U), dev(theta), ohw, n_ones=3, want_idx=True)
+    ref_out, ref_idx = cgeom.homo_warp(torch.cat([U, torch.ones_like(U)], 1).numpy(), theta.numpy(), ohw)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(out.cpu().numpy(), ref_out)
+
+
+def test_homo_warp_horizon_and_identity(ops):
+    """edge cases: t ~ 0 (divide guard, INT_MIN cast) and identity theta (not an identity warp)."""
+    U = torch.rand(1, 1, 32, 32, generator=g(41))
+    for th in ([1, 0, 0, 0, 1, 0, 0, 0, 1], [1, 0, 0, 0, 1, 0, 1, 0, 0], [1, 0, 0, 0, 1, 0, 5, 5, 1e-8], [0] * 9):
+        theta = torch.tensor([th], dtype=torch.float32)
+        out, idx = ops.homo_warp(dev(U), dev(theta), (32, 32), want_idx=True)
+        ref_out, ref_idx = cgeom.homo_warp(U.numpy(), theta.numpy(), (32, 32))
+        assert np.array_equal(idx.cpu().numpy(), ref_idx), th
+        a, b = out.cpu().numpy(), ref_out
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b)), th
+
+
+def test_dlt_and_mat3(ops, golden_ops):
+    src, dst = T(golden_ops["dlt_src"]), T(golden_ops["dlt_dst"])
+    H = torch.empty(5, 3, 3, device="cuda")
+    ops.dlt4(dev(src[0]), dev(dst - src), H, 5, 1.0, 1.0, 1.0)
+    assert (H.cpu() - T(golden_ops["dlt_H"])).abs().max() < 2e-4
+    ops.dlt4(dev(src[0]), dev(dst - src), H, 5, 1.0, 1.0, 8.0)
+    assert (H.cpu() - geom.dlt4(src / 8, dst / 8)).abs().max() < 2e-4
+    M = torch.tensor([[32., 0, 32], [0, 24, 24], [0, 0, 1]])
+    Hc = T(golden_ops["dlt_H"])
+    out = torch.empty(5, 3, 3, device="cuda")
+    ops.mat3_sandwich(dev(torch.inverse(M)), dev(Hc), dev(M), out)
+    assert (out.cpu() - torch.inverse(M) @ Hc @ M).abs().max() < 1e-4
+    ops.mat3_sandwich(dev(torch.inverse(M)), dev(Hc), dev(M), out, invert=True)
+    assert (out.cpu() - torch.inverse(M) @ torch.inverse(Hc) @ M).abs().max() < 1e-4
+
+
+def test_mesh_bounds(ops, golden_ops):
+    out = torch.empty(4, device="cuda")
+    ops.mesh_bounds(dev(T(golden_ops["mesh_H"])), out, 400, 300)
+    assert (out.cpu() - T(golden_ops["mesh_minmax"])).abs().max() < 1e-3
+
+
+def test_flow_warp_resize(ops, golden_ops):
+    x, fij = T(golden_ops["warp_x"]), T(golden_ops["flow_ij"])
+    out = ops.flow_warp(dev(x), dev(fij))
+    assert (out.cpu() - T(golden_ops["warp_out"])).abs().max() < 1e-3      # warped-pixel L_inf < 1e-3
+    mul = torch.rand(2, 1, 48, 64, generator=g(42))
+    out2 = ops.flow_warp(dev(x), dev(fij), dev(mul))
+    assert (out2.cpu() - T(golden_ops["warp_out"]) * mul).abs().max() < 1e-3
+    big = fij * 50                                                          # mostly out of bounds
+    assert (ops.flow_warp(dev(x), dev(big)).cpu() - geom.warp(x, big)).abs().max() < 1e-3
+    r = ops.resize_bilinear(dev(fij), 60, 100, True, div=(64 / 100.0, 48 / 60.0))
+    assert (r.cpu() - T(golden_ops["resize_flow_out"])).abs().max() < 1e-5
+    rin = T(golden_ops["resize512_in"])
+    r5 = ops.resize_bilinear(dev(rin), 512, 512, False)
+    assert (r5.cpu() - geom.resize512(rin)).abs().max() < 1e-4
+
+
+def test_range_map_occlusion_open(ops, golden_ops):
+    fji = T(golden_ops["flow_ji"])
+    rm = ops.range_map(dev(fji))
+    assert (rm.cpu() - T(golden_ops["range_map"])).abs().max() < 1e-5
+    rm2 = ops.range_map(dev(fji))
+    assert torch.equal(rm, rm2)                                             # deterministic splat
+    occ = ops.occlusion_from_range(rm, False)
+    assert (occ.cpu() - T(golden_ops["occlusion"])).abs().max() < 1e-5
+    hard = ops.occlusion_from_range(rm, True).cpu()
+    want = (T(golden_ops["occlusion"]) >= 0.5).float()
+    near = (T(golden_ops["occlusion"]) - 0.5).abs() < 1e-5
+    assert torch.equal(hard[~near], want[~near])
+    m = T(golden_ops["open_in"])
+    assert torch.equal(ops.morph_open(dev(m)).cpu(), T(golden_ops["open_out"]))
+    m2 = (torch.rand(2, 3, 70, 45, generator=g(43)) > 0.004).float()
+    assert torch.equal(ops.morph_open(dev(m2)).cpu(), geom.morph_open19(m2))
+
+
+def test_tps(ops, golden_ops):
+    U, src, tgt = T(golden_ops["tps_U"]), T(golden_ops["tps_source"]), T(golden_ops["tps_target"])
+    out, Tm = ops.tps_transform(dev(U), dev(src), dev(tgt), (24, 28))
+    ref_out, ref_T = geom.tps_transformer(U, src, tgt, (24, 28))
+    assert (Tm.cpu() - ref_T).abs().max() < 1e-4 * max(1.0, ref_T.abs().max().item())
+    d = (out.cpu() - ref_out).abs()
+    # K=172 fp32 contraction with cancellation: sample positions agree to ~1e-4 px, values on a 0..255
+    # noise image to a few 1e-2 (the reference itself differs from the oracle by this much across hosts)
+    assert np.percentile(d.numpy(), 99) < 2e-2 and d.mean() < 2e-3 and d.max() < 2.0
+
+
+def test_blend_and_eval_finish(ops):
+    gg = g(44)
+    h, w = 37, 53
+    homo1, homo2 = torch.rand(1, 6, h, w, generator=gg) * 255, torch.rand(1, 6, h, w, generator=gg) * 255
+    for t in (homo1, homo2):
+        t[:, 3:] = (t[:, 3:] > 100).float()
+    fin = torch.rand(1, 6, h, w, generator=gg) * 255
+    fin[:, 3:] = (fin[:, 3:] > 60).float()
+    occ = (torch.rand(1, 1, h, w, generator=gg) > 0.3).float()
+    f = fin * occ
+    o1, m1 = homo1[:, :3], homo1[:, 3:]
+    o2, m2 = f[:, :3], f[:, 3:]
+    nov = 1 - m1
+    o2r = homo2[:, :3] * (1 - m2) * nov + o2 * m2
+    m2r = homo2[:, 3:] * (1 - m2) * nov + m2 * m2
+    bl = torch.nan_to_num(((o1 * m1 + o2r * m2r) / (m1 + m2r)).clip(0, 255), nan=0.0).to(torch.uint8)
+    find = dev(fin)
+    go2, gm1, gm2, gbl = ops.blend(dev(homo1), dev(homo2), find, dev(occ))
+    assert (find.cpu() - f).abs().max() == 0
+    assert (go2.cpu() - o2r).abs().max() < 1e-4
+    assert (gbl.cpu().int() - bl.int()).abs().max() <= 1 and (gbl.cpu() != bl).float().mean() < 1e-3
+    assert (gm1.cpu() - m1.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1)).abs().max() < 1e-6
+    assert (gm2.cpu() - m2r.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1)).abs().max() < 1e-6
+    fin6 = torch.rand(2, 6, h, w, generator=gg)
+    occ2 = (torch.rand(2, 1, h, w, generator=gg) > 0.5).float()
+    fd = dev(fin6)
+    ov = ops.eval_finish(fd, dev(occ2))
+    assert torch.equal(ov.cpu(), (fin6[:, 3:6].mean(1) < 0.9).float()) or (ov.cpu() != (fin6[:, 3:6].mean(1) < 0.9).float()).sum() <= 1
+    assert (fd.cpu() - fin6 * occ2).abs().max() == 0
+    mt = ops.mean_threshold(dev(fin6[:, 3:6].contiguous()), 0.5)
+    assert (mt.cpu() != (fin6[:, 3:6].mean(1, keepdim=True) > 0.5).float()).sum() <= 1
