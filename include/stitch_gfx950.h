@@ -72,9 +72,11 @@ int st_maxpool_nhwc(const float* x, float* out, int32_t B, int32_t H, int32_t W,
 int st_dwconv3x3_residual(const float* x, const float* w, const float* bias, float* out, int32_t B,
                           int32_t H, int32_t W, int32_t C, void* stream);
 /* LinearPositionEmbeddingSine (attention.py:156-161); coords [rows, ldc]=(x,y) or implicit grid
- * (row -> (row % Wg, row / Wg), optionally modulo ws), value*cscale + coff; write or accumulate.   */
+ * (r = row % period; r -> (r % Wg, r / Wg), optionally modulo ws), value*cscale + coff; write or
+ * accumulate.                                                                                      */
 int st_sine_pe(float* out, int32_t ld, int32_t rows, int32_t dim, const float* coords, int32_t ldc,
-               int32_t Wg, int32_t ws, float cscale, float coff, int32_t accumulate, void* stream);
+               int32_t Wg, int32_t ws, int32_t period, float cscale, float coff, int32_t accumulate,
+               void* stream);
 /* Multi-head softmax attention, element (b, t, h, e) at base + b*bs + t*ts + h*D + e (floats).
  *   _small : one thread per query, K/V from L2 (attention.py:9-68; 8 latents / 1x8 decoder query)
  *   _kvlds : K/V slab (Nk <= 256) staged in LDS (GSA: twins.py:336-392,633-680)                     */

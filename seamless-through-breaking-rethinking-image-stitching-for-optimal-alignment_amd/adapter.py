@@ -1,0 +1,179 @@
+"""Drop-in ``FlowHomoAdpater`` (reference: core/flowHomoAdpater.py:38-377) on the MI355X kernels.
+
+Same constructor, same ``forward(input1_tensor, input2_tensor, type, pad_mode, preprocess_callback)``,
+same output-dict keys / shapes / dtypes, same checkpoint key set (``homo_backbone.*``,
+``flow_backbone.*``; a DataParallel ``module.`` prefix is accepted).  Inputs are float32
+``[B,3,H,W]`` RGB in 0..255.  Everything below runs in HIP kernels through the C-ABI; PyTorch only
+owns the device buffers.  The live configuration is the shipped one (configs/last_config.py +
+inf_configs/*): only_homo=False, use_forward=False, use_combine_h_flow=False,
+use_fb_consistency_mask=True, test_not_use_combine_h_flow=True, use_whole_resolution=False; the
+reference's other branches raise ``NotImplementedError`` here exactly where they are dead/buggy there.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def preprocess_occlusion_mask(occlusion_mask, kernel_size=(19, 19)):
+    """reference: core/flowHomoAdpater.py:18-35 (threshold, 19x19 morphological open)."""
+    if kernel_size[0] != kernel_size[1]:
+        raise NotImplementedError("square kernels only")
+    return ops.morph_open(occlusion_mask.contiguous(), kernel_size[0])
+
+
+def _flag(cfg, name, default=False):
+    return getattr(cfg, name) if hasattr(cfg, name) else default
+
+
+class FlowHomoAdpater(nn.Module):
+    def __init__(self, homo_backbone, flow_backbone, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.use_forward = _flag(cfg, "use_forward")
+        self.detach_H = _flag(cfg, "detach_H")
+        self.detach_flow = _flag(cfg, "detach_flow")
+        self.homo_backbone = homo_backbone
+        self.flow_backbone = flow_backbone
+        self._host = {}
+
+    # checkpoints saved from DataParallel carry a "module." prefix (out.py:80-85)
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        if state_dict and all(k.startswith("module.") for k in state_dict):
+            state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
+        return super().load_state_dict(state_dict, strict=strict)
+
+    # ------------------------------------------------------------------ small host-side constants
+    def _mat(self, dev, key, rows):
+        k = (key, str(dev))
+        if k not in self._host:
+            self._host[k] = torch.tensor(rows, dtype=torch.float32).to(dev)
+        return self._host[k]
+
+    def _scale_pair(self, dev, w, h):
+        """M = [[w/2,0,w/2],[0,h/2,h/2],[0,0,1]] and its inverse (flowHomoAdpater.py:98-107)."""
+        k = ("scale", float(w), float(h), str(dev))
+        if k not in self._host:
+            M = torch.tensor([[w / 2.0, 0., w / 2.0], [0., h / 2.0, h / 2.0], [0., 0., 1.]], dtype=torch.float32)
+            self._host[k] = (M.to(dev), torch.inverse(M).contiguous().to(dev))
+        return self._host[k]
+
+    def _corners(self, dev, w, h):
+        return self._mat(dev, ("corners", float(w), float(h)), [[0., 0.], [w, 0.], [0., h], [w, h]])
+
+    # ------------------------------------------------------------------ reference surface
+    def predict_homo(self, input1_tensor, input2_tensor):
+        """[0,255] -> corner offsets [B,4,2] (flowHomoAdpater.py:53-61); x/127.5 - 1 is fused into the prep."""
+        off = self.homo_backbone.offsets_from_images(input1_tensor, input2_tensor, 1.0, 127.5, 1.0)
+        return off.reshape(-1, 4, 2)
+
+    def predict_flow(self, input1_tensor, input2_tensor):
+        """flow 1->2 at full resolution, eval: list of one tensor (flowHomoAdpater.py:63-70)."""
+        return [self.flow_backbone.flow_rows(input1_tensor, input2_tensor)[0]]
+
+    def forward(self, input1_tensor, input2_tensor, type="train", pad_mode="constant", preprocess_callback=None):
+        if not input1_tensor.is_cuda:
+            raise RuntimeError("FlowHomoAdpater (gfx950) needs CUDA/HIP tensors: there is no CPU fallback")
+        input1_tensor = input1_tensor.float().contiguous()
+        input2_tensor = input2_tensor.float().contiguous()
+        with torch.no_grad():
+            if type == "test_out":
+                return self.test_out_forward(input1_tensor, input2_tensor, pad_mode=pad_mode,
+                                             preprocess_callback=preprocess_callback)
+            if type == "train" or type == "test_eval":
+                return self.train_eval_foward(input1_tensor, input2_tensor)
+            raise NotImplementedError
+
+    # ------------------------------------------------------------------ eval @ fixed size (:83-191)
+    def train_eval_foward(self, input1_tensor, input2_tensor):
+        if self.use_forward or _flag(self.cfg, "use_combine_h_flow") or _flag(self.cfg, "only_homo"):
+            raise NotImplementedError("only the shipped branch (flowHomoAdpater.py:165-186) is implemented")
+        dev = input1_tensor.device
+        B, _, img_h, img_w = input1_tensor.shape
+        motion = self.predict_homo(input1_tensor, input2_tensor)
+        H = torch.empty((B, 3, 3), device=dev)
+        ops.dlt4(self._corners(dev, img_w, img_h), motion.contiguous(), H, B, 1.0, 1.0, 8.0)          # :96
+        M, Minv = self._scale_pair(dev, img_w / 8, img_h / 8)
+        H_mat, H_inv_mat = torch.empty_like(H), torch.empty_like(H)
+        ops.mat3_sandwich(Minv, H, M, H_mat)                                                           # :108
+        ops.mat3_sandwich(Minv, H, M, H_inv_mat, invert=True)                                          # :112
+        output_H = ops.homo_warp(input2_tensor, H_mat.view(B, 9), (img_h, img_w), n_ones=3)            # :111
+        output_H_inv = ops.homo_warp(input1_tensor, H_inv_mat.view(B, 9), (img_h, img_w), n_ones=3)    # :113
+        warp2 = output_H[:, 0:3].contiguous()
+        flow_ij = self.predict_flow(input1_tensor, warp2)[0]                                           # :167
+        final = ops.flow_warp(output_H, flow_ij)                                                       # :170
+        out = dict()
+        if _flag(self.cfg, "use_fb_consistency_mask", True):
+            flow_ji = self.predict_flow(warp2, input1_tensor)[0]                                       # :178
+            occ = ops.occlusion_from_range(ops.range_map(flow_ji), True)                               # :180-181
+        else:
+            occ = torch.ones((B, 1, img_h, img_w), device=dev)
+        overlap = ops.eval_finish(final, occ)                                                          # :171-174,182
+        if _flag(self.cfg, "use_fb_consistency_mask", True):
+            out.update(origin_occlusion_mask=occ.squeeze(1))
+        out.update(output_H=output_H, output_H_inv=output_H_inv, final_warp_output=final, overlap=overlap,
+                   flow_predictions=[flow_ij], H=H)
+        return out
+
+    # ------------------------------------------------------------------ stitching @ native size (:197-377)
+    def test_out_forward(self, input1_tensor, input2_tensor, pad_mode="constant", preprocess_callback=None):
+        if self.use_forward:
+            raise NotImplementedError
+        if not _flag(self.cfg, "test_not_use_combine_h_flow", True) or _flag(self.cfg, "use_whole_resolution"):
+            raise NotImplementedError
+        dev = input1_tensor.device
+        B, _, img_h, img_w = input1_tensor.shape
+        if B != 1:
+            raise NotImplementedError("test_out shares one data-dependent canvas: batch must be 1 (as in out.py:37)")
+        a512 = ops.resize_bilinear(input1_tensor, 512, 512, False)                                     # :204-205
+        b512 = ops.resize_bilinear(input2_tensor, 512, 512, False)
+        motion = self.predict_homo(a512, b512).contiguous()
+        H512 = torch.empty((B, 3, 3), device=dev)
+        ops.dlt4(self._corners(dev, 512., 512.), motion, H512, B, 1.0, 1.0, 1.0)                       # :216
+        M5, M5inv = self._scale_pair(dev, 512., 512.)
+        th = torch.empty_like(H512)
+        ops.mat3_sandwich(M5inv, H512, M5, th)
+        out_H = ops.homo_warp(b512, th.view(B, 9), (512, 512), n_ones=3)                               # :230
+        warp2_512 = out_H[:, 0:3].contiguous()
+        warp_mask_512 = ops.mean_threshold(out_H[:, 3:6].contiguous(), 0.5)                            # :233-234
+        flow512 = self.predict_flow(a512, warp2_512)[0]                                                # :236
+        residual = ops.resize_bilinear(flow512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))  # :241
+        H = torch.empty((B, 3, 3), device=dev)
+        ops.dlt4(self._corners(dev, float(img_w), float(img_h)), motion, H, B, img_w / 512.0, img_h / 512.0, 1.0)  # :244-253
+        bounds = torch.empty((4,), device=dev)
+        ops.mesh_bounds(H, bounds, img_w, img_h)                                                       # :254-266
+        mnx, mxx, mny, mxy = bounds.tolist()                                                           # the path's host sync (:268,367)
+        width_max, width_min = int(max(float(img_w), mxx)), int(min(0.0, mnx))                         # .int() truncation
+        height_max, height_min = int(max(float(img_h), mxy)), int(min(0.0, mny))
+        out_width, out_height = width_max - width_min, height_max - height_min                         # :270-271
+        Mt = torch.tensor([[out_width / 2.0, 0., out_width / 2.0], [0., out_height / 2.0, out_height / 2.0], [0., 0., 1.]])
+        Nt = torch.tensor([[img_w / 2.0, 0., img_w / 2.0], [0., img_h / 2.0, img_h / 2.0], [0., 0., 1.]])
+        Ninv = torch.inverse(Nt).contiguous()
+        I_ = torch.tensor([[1., 0., float(width_min)], [0., 1., float(height_min)], [0., 0., 1.]])
+        I_mat = torch.matmul(torch.matmul(Ninv, I_), Mt).unsqueeze(0).contiguous().to(dev)                          # :291 (3x3 host constants)
+        canvas = (out_height, out_width)
+        homo_output = ops.homo_warp(input1_tensor, I_mat.view(1, 9), canvas, n_ones=3)                 # :292
+        ident = self._mat(dev, "eye", [[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]])
+        Hc = torch.empty_like(H)
+        ops.mat3_sandwich(ident, H, I_.to(dev), Hc)                                                    # H @ I_  (:306)
+        H_mat = torch.empty_like(H)
+        ops.mat3_sandwich(Ninv.to(dev), Hc, Mt.to(dev), H_mat)                                         # :307
+        homo_output2 = ops.homo_warp(input2_tensor, H_mat.view(B, 9), canvas, n_ones=3)                # :310
+        rf = ops.homo_warp(residual, I_mat.view(1, 9), canvas, n_ones=1)                               # :313-314
+        final = ops.flow_warp(homo_output2, rf[:, 0:2].contiguous(), rf[:, 2:3].contiguous())          # :316-317
+        if not _flag(self.cfg, "use_fb_consistency_mask", True):
+            raise NotImplementedError("shipped inference config sets use_fb_consistency_mask=True")
+        back512 = self.predict_flow(warp2_512, a512)[0]                                                # :326
+        back = ops.resize_bilinear(back512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))
+        occ = ops.occlusion_from_range(ops.range_map(back), False)                                     # :332
+        origin_occ = ops.morph_open(occ, 19)                                                           # :333-334
+        occ_c = ops.homo_warp(origin_occ, I_mat.view(1, 9), canvas)                                    # :335
+        occ_c = ops.morph_open(occ_c, 19)                                                              # :336
+        output2, mask1, mask2, blend = ops.blend(homo_output, homo_output2, final, occ_c)              # :339-360
+        return dict(H_warp=homo_output2[:, 0:3], final_warp=final[:, 0:3], output1=homo_output[:, 0:3], output2=output2,
+                    mask1=mask1, mask2=mask2, blend_image=blend, residual_flow=residual, width_min=width_min,
+                    height_min=height_min, out_height=out_height, out_width=out_width, H=Hc, warp_input2_mask=warp_mask_512,
+                    warp_input2_tensor_512=warp2_512, I_mat=I_mat, H_warp_mask=homo_output2[:, 3:6], occlusion_mask=occ_c,
+                    origin_occlusion_mask=origin_occ)

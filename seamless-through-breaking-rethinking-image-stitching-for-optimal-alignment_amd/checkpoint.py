@@ -1,0 +1,264 @@
+"""Checkpoint surface of the drop-in modules.
+
+The reference loads one flat ``state_dict`` of ``DataParallel(FlowHomoAdpater)`` with ``strict=True``
+(out.py:76-85, evaluate.py:119-123).  ``homo_spec`` / ``flow_spec`` enumerate that key set (699 tensors,
+94.2 M elements; names follow core/UDIS2/Homography/network.py:14-118, torchvision ResNet-50,
+core/FlowFormer/PerCostFormer3/*.py and timm-0.4.12 Twins) and ``ParamTree`` materialises it as a
+nested ``nn.Module`` so ``state_dict()`` / ``load_state_dict(strict=True)`` see exactly those names.
+The kernels never read these tensors directly: ``pack`` steps re-lay them out for the GPU
+(channels-last GEMM operands, BN folded, fused projections) once per load.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+# live hyper-parameters (reference: configs/last_config.py:1, key "percostformer3")
+HP = dict(
+    cost_latent_input_dim=64, cost_latent_token_num=8, cost_latent_dim=128,
+    encoder_depth=3, encoder_latent_dim=256, vert_c_dim=64, query_latent_dim=64,
+    decoder_depth=12, patch_size=8, gt_r=15, cost_heads_num=1,
+)
+
+
+def _lin(d, name, cin, cout, bias=True):
+    d[name + ".weight"] = (cout, cin)
+    if bias:
+        d[name + ".bias"] = (cout,)
+
+
+def _conv(d, name, cin, cout, kh, kw=None, bias=True, groups=1):
+    kw = kh if kw is None else kw
+    d[name + ".weight"] = (cout, cin // groups, kh, kw)
+    if bias:
+        d[name + ".bias"] = (cout,)
+
+
+def _ln(d, name, c):
+    d[name + ".weight"] = (c,)
+    d[name + ".bias"] = (c,)
+
+
+def _bn(d, name, c):
+    d[name + ".weight"] = (c,)
+    d[name + ".bias"] = (c,)
+    d[name + ".running_mean"] = (c,)
+    d[name + ".running_var"] = (c,)
+    d[name + ".num_batches_tracked"] = ()
+
+
+def _bottleneck(d, name, inplanes, planes, downsample):
+    # torchvision ResNet-50 v1.5 Bottleneck (stride sits on conv2)
+    _conv(d, name + ".conv1", inplanes, planes, 1, bias=False)
+    _bn(d, name + ".bn1", planes)
+    _conv(d, name + ".conv2", planes, planes, 3, bias=False)
+    _bn(d, name + ".bn2", planes)
+    _conv(d, name + ".conv3", planes, planes * 4, 1, bias=False)
+    _bn(d, name + ".bn3", planes * 4)
+    if downsample:
+        _conv(d, name + ".downsample.0", inplanes, planes * 4, 1, bias=False)
+        _bn(d, name + ".downsample.1", planes * 4)
+
+
+def _res_layer(d, name, inplanes, planes, blocks):
+    for i in range(blocks):
+        _bottleneck(d, f"{name}.{i}", inplanes if i == 0 else planes * 4, planes, i == 0)
+
+
+def homo_spec(prefix=""):
+    d = OrderedDict()
+    chans = [(2, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256)]
+    for idx, (ci, co) in zip([0, 2, 5, 7, 10, 12], chans):
+        _conv(d, f"regressNet1_part1.{idx}", ci, co, 3, bias=False)
+    _lin(d, "regressNet1_part2.0", 4096, 4096)
+    _lin(d, "regressNet1_part2.2", 4096, 1024)
+    _lin(d, "regressNet1_part2.4", 1024, 8)
+    # dead mesh head, still part of the checkpoint (network.py:48-85)
+    chans2 = chans + [(256, 512), (512, 512)]
+    for idx, (ci, co) in zip([0, 2, 5, 7, 10, 12, 15, 17], chans2):
+        _conv(d, f"regressNet2_part1.{idx}", ci, co, 3, bias=False)
+    _lin(d, "regressNet2_part2.0", 8192, 4096)
+    _lin(d, "regressNet2_part2.2", 4096, 2048)
+    _lin(d, "regressNet2_part2.4", 2048, 13 * 13 * 2)
+    # ResNet-50 conv1..layer2 / layer3 (network.py:103-118)
+    _conv(d, "feature_extractor_stage1.0", 3, 64, 7, bias=False)
+    _bn(d, "feature_extractor_stage1.1", 64)
+    _res_layer(d, "feature_extractor_stage1.4", 64, 64, 3)
+    _res_layer(d, "feature_extractor_stage1.5", 256, 128, 4)
+    _res_layer(d, "feature_extractor_stage2.0", 512, 256, 6)
+    return OrderedDict((prefix + k, v) for k, v in d.items())
+
+
+def _twins_block(d, name, dim, kind, sr):
+    _ln(d, name + ".norm1", dim)
+    if kind == "lsa":
+        _lin(d, name + ".attn.qkv", dim, dim * 3)
+        _lin(d, name + ".attn.proj", dim, dim)
+    else:
+        _lin(d, name + ".attn.q", dim, dim)
+        _lin(d, name + ".attn.kv", dim, dim * 2)
+        _lin(d, name + ".attn.proj", dim, dim)
+        _conv(d, name + ".attn.sr", dim, dim, sr)
+        _ln(d, name + ".attn.norm", dim)
+    _ln(d, name + ".norm2", dim)
+    _lin(d, name + ".mlp.fc1", dim, dim * 4)
+    _lin(d, name + ".mlp.fc2", dim * 4, dim)
+
+
+def twins_spec(prefix):
+    """timm twins_svt_large with stages 3-4 deleted (encoders.py:7-19)."""
+    d = OrderedDict()
+    dims, srs = [128, 256], [8, 4]
+    _conv(d, "patch_embeds.0.proj", 3, 128, 4)
+    _ln(d, "patch_embeds.0.norm", 128)
+    _conv(d, "patch_embeds.1.proj", 128, 256, 2)
+    _ln(d, "patch_embeds.1.norm", 256)
+    for s in range(2):
+        _twins_block(d, f"blocks.{s}.0", dims[s], "lsa", srs[s])
+        _twins_block(d, f"blocks.{s}.1", dims[s], "gsa", srs[s])
+    for s in range(2):
+        _conv(d, f"pos_block.{s}.proj.0", dims[s], dims[s], 3, groups=dims[s])
+    _ln(d, "norm", 1024)  # final norm of the full model survives ``del`` (unused)
+    return OrderedDict((prefix + k, v) for k, v in d.items())
+
+
+def _attn_layer(d, name, qdim, tdim, qk, v):
+    _ln(d, name + ".norm1", qdim)
+    _ln(d, name + ".norm2", qdim)
+    _lin(d, name + ".q", qdim, qk)
+    _lin(d, name + ".k", tdim, qk)
+    _lin(d, name + ".v", tdim, v)
+    _lin(d, name + ".proj", v, qdim)
+    _lin(d, name + ".ffn.0", qdim, qdim)
+    _lin(d, name + ".ffn.3", qdim, qdim)
+
+
+def _vert_block(d, name, dim, cdim, latent, is_global, sr=4):
+    _ln(d, name + ".norm1", dim)
+    a = name + ".attn"
+    _lin(d, a + ".context_proj", latent, cdim)
+    _lin(d, a + ".q", dim + cdim, dim)
+    _lin(d, a + ".k", dim if is_global else dim + cdim, dim)
+    _lin(d, a + ".v", dim, dim)
+    _lin(d, a + ".proj", dim, dim)
+    if is_global:
+        _conv(d, a + ".sr_key", dim + cdim, dim, sr)
+        _conv(d, a + ".sr_value", dim, dim, sr)
+        _ln(d, a + ".norm", dim)
+    _ln(d, name + ".norm2", dim)
+    _lin(d, name + ".mlp.fc1", dim, dim * 4)
+    _lin(d, name + ".mlp.fc2", dim * 4, dim)
+
+
+def flow_spec(prefix=""):
+    hp = HP
+    d = OrderedDict()
+    E = hp["cost_latent_input_dim"]
+    D = hp["cost_latent_dim"]
+    Q = hp["query_latent_dim"]
+    # --- memory encoder (encoder.py:328-357, 174-223)
+    d.update(twins_spec("memory_encoder.feat_encoder.svt."))
+    cpe = "memory_encoder.cost_perceiver_encoder."
+    _conv(d, cpe + "patch_embed.proj.0", 1, E // 4, 6)
+    _conv(d, cpe + "patch_embed.proj.2", E // 4, E // 2, 6)
+    _conv(d, cpe + "patch_embed.proj.4", E // 2, E, 6)
+    _conv(d, cpe + "patch_embed.ffn_with_coord.0", E + 64, E + 64, 1)
+    _conv(d, cpe + "patch_embed.ffn_with_coord.2", E + 64, E + 64, 1)
+    _ln(d, cpe + "patch_embed.norm", E + 64)
+    d[cpe + "latent_tokens"] = (1, hp["cost_latent_token_num"], D)
+    _attn_layer(d, cpe + "input_layer", D, 2 * E, D, D)
+    for i in range(hp["encoder_depth"]):
+        _attn_layer(d, cpe + f"encoder_layers.{i}", D, D, D, D)
+    for i in range(hp["encoder_depth"]):
+        v = cpe + f"vertical_encoder_layers.{i}"
+        _vert_block(d, v + ".local_block", D, hp["vert_c_dim"], hp["encoder_latent_dim"], False)
+        _vert_block(d, v + ".global_block", D, hp["vert_c_dim"], hp["encoder_latent_dim"], True)
+    # --- memory decoder (decoder.py:138-212)
+    md = "memory_decoder."
+    _conv(d, md + "flow_token_encoder.0", 81, Q, 1)
+    _conv(d, md + "flow_token_encoder.2", Q, Q, 1)
+    _conv(d, md + "pretrain_head.0", Q, 2 * Q, 1)
+    _conv(d, md + "pretrain_head.2", 2 * Q, 2 * Q, 1)
+    _conv(d, md + "pretrain_head.4", 2 * Q, hp["gt_r"] ** 2, 1)
+    _conv(d, md + "proj", hp["encoder_latent_dim"], 256, 1)
+    _attn_layer(d, md + "decoder_layer.cross_attend", Q, D, Q, Q)
+    ub = md + "update_block."
+    _conv(d, ub + "encoder.convc1", 81 + Q, 256, 1)
+    _conv(d, ub + "encoder.convc2", 256, 192, 3)
+    _conv(d, ub + "encoder.convf1", 2, 128, 7)
+    _conv(d, ub + "encoder.convf2", 128, 64, 3)
+    _conv(d, ub + "encoder.conv", 64 + 192, 126, 3)
+    for g in ("z", "r", "q"):
+        _conv(d, ub + f"gru.conv{g}1", 512, 128, 1, 5)
+    for g in ("z", "r", "q"):
+        _conv(d, ub + f"gru.conv{g}2", 512, 128, 5, 1)
+    _conv(d, ub + "flow_head.conv1", 128, 256, 3)
+    _conv(d, ub + "flow_head.conv2", 256, 2, 3)
+    _conv(d, ub + "mask.0", 128, 256, 3)
+    _conv(d, ub + "mask.2", 256, 576, 1)
+    _conv(d, ub + "aggregator.to_v", 128, 128, 1, bias=False)
+    d[ub + "aggregator.gamma"] = (1,)
+    _conv(d, md + "att.to_qk", 128, 256, 1, bias=False)
+    d[md + "att.pos_emb.rel_height.weight"] = (2 * 160 - 1, 128)
+    d[md + "att.pos_emb.rel_width.weight"] = (2 * 160 - 1, 128)
+    d[md + "att.pos_emb.rel_ind"] = (160, 160)
+    # --- context encoder (transformer.py:32)
+    d.update(twins_spec("context_encoder.svt."))
+    return OrderedDict((prefix + k, v) for k, v in d.items())
+
+
+
+
+_BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked", "rel_ind")
+
+
+class ParamTree(nn.Module):
+    """Nested parameter container reproducing a dotted key set."""
+
+    def __init__(self, spec=None):
+        super().__init__()
+        for key, shape in (spec or {}).items():
+            self._add(key.split("."), key, tuple(shape))
+
+    def _add(self, parts, key, shape):
+        if len(parts) > 1:
+            if parts[0] not in self._modules:
+                self.add_module(parts[0], ParamTree())
+            self._modules[parts[0]]._add(parts[1:], key, shape)
+            return
+        leaf = parts[0]
+        if leaf == "num_batches_tracked":
+            self.register_buffer(leaf, torch.zeros((), dtype=torch.int64))
+        elif leaf == "rel_ind":
+            n = shape[0]
+            self.register_buffer(leaf, (torch.arange(n).view(1, -1) - torch.arange(n).view(-1, 1)) + n - 1)
+        elif leaf in _BUFFER_LEAVES:
+            self.register_buffer(leaf, torch.ones(shape) if leaf == "running_var" else torch.zeros(shape))
+        else:
+            self.register_parameter(leaf, nn.Parameter(_default_init(key, leaf, shape), requires_grad=False))
+
+
+def _default_init(key, leaf, shape):
+    """Random initialisation of the architecture (no checkpoint is available offline)."""
+    if leaf == "bias":
+        return torch.zeros(shape)
+    if leaf == "gamma":
+        return torch.zeros(shape)
+    if leaf == "weight" and len(shape) == 1:
+        return torch.ones(shape)
+    if leaf == "latent_tokens":
+        return torch.randn(shape)
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    return torch.randn(shape) * (1.0 / max(fan_in, 1)) ** 0.5
+
+
+def flat_params(module, prefix=""):
+    """{key: tensor} of parameters + buffers (detached), i.e. ``state_dict()`` without copies."""
+    out = OrderedDict()
+    for k, v in module.state_dict(prefix=prefix).items():
+        out[k] = v.detach()
+    return out

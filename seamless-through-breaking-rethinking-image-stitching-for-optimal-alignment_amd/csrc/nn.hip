@@ -189,7 +189,7 @@ extern "C" int st_dwconv3x3_residual(const float* x, const float* w, const float
 // [sin x | cos x | sin y | cos y].  Coordinates come either from `coords` ([rows, ldc] = x, y) or
 // from the row index on a Wg-wide grid (optionally window-local modulo ws), scaled + offset.
 __global__ void sine_pe_kernel(float* __restrict__ out, int ld, int rows, int dim, const float* __restrict__ coords,
-                               int ldc, int Wg, int ws, float cscale, float coff, int accumulate) {
+                               int ldc, int Wg, int ws, int period, float cscale, float coff, int accumulate) {
     const int q = dim >> 2;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)rows * q) return;
@@ -197,7 +197,8 @@ __global__ void sine_pe_kernel(float* __restrict__ out, int ld, int rows, int di
     float x, y;
     if (coords) { x = coords[(size_t)row * ldc]; y = coords[(size_t)row * ldc + 1]; }
     else {
-        int gx = row % Wg, gy = row / Wg;
+        const int pr = period > 0 ? row % period : row;
+        int gx = pr % Wg, gy = pr / Wg;
         if (ws > 0) { gx %= ws; gy %= ws; }
         x = (float)gx * cscale + coff; y = (float)gy * cscale + coff;
     }
@@ -210,11 +211,11 @@ __global__ void sine_pe_kernel(float* __restrict__ out, int ld, int rows, int di
 }
 
 extern "C" int st_sine_pe(float* out, int32_t ld, int32_t rows, int32_t dim, const float* coords, int32_t ldc, int32_t Wg,
-                          int32_t ws, float cscale, float coff, int32_t accumulate, void* stream) {
+                          int32_t ws, int32_t period, float cscale, float coff, int32_t accumulate, void* stream) {
     if (!out || rows <= 0 || dim <= 0 || dim % 4 || (!coords && Wg <= 0)) return ST_EINVAL;
     const size_t total = (size_t)rows * (dim / 4);
     hipLaunchKernelGGL(sine_pe_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, ld, rows, dim,
-                       coords, ldc, Wg, ws, cscale, coff, accumulate);
+                       coords, ldc, Wg, ws, period, cscale, coff, accumulate);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -1,0 +1,496 @@
+"""FlowFormer++ (PerCostFormer3) flow estimator on the MI355X kernels -- drop-in for
+``build_flowformer(cfg)`` / ``FlowFormer.forward`` (reference: core/FlowFormer/__init__.py:2-9,
+core/FlowFormer/PerCostFormer3/transformer.py:47-65).
+
+Design notes (MI355X-first, not a translation):
+  * activations are channels-last rows ``[B*H*W, C]``; every Linear / conv is one fp32-MFMA implicit
+    GEMM (st_conv_gemm) with bias / activation / residual / GRU gating fused in the epilogue, and
+    channel concatenations are column slices of one wide buffer (no cat / permute passes);
+  * the 8 latent tokens stay in ``[pixel, latent, C]`` order for the whole cost encoder; the
+    "vertical" Twins layers address that layout with strides instead of transposing it
+    (encoder.py:277-279 permutes twice per layer);
+  * context / positional terms that the reference concatenates to every token and re-projects per
+    latent (twins.py:261-264,285-288,340-377) are linear, so they are folded into per-position bias
+    tables computed once per layer (4096 rows instead of 8*4096) and added in the GEMM epilogue;
+  * only the last of the 12 convex upsamplings is used in eval (decoder.py:341-344): the mask head
+    runs on the last iteration only.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .checkpoint import HP, ParamTree, flat_params, flow_spec
+from .homography import pack_conv
+
+
+def _new(rows, cols, dev, zero=False):
+    return (torch.zeros if zero else torch.empty)((rows, cols), device=dev, dtype=torch.float32)
+
+
+class FlowFormer(ParamTree):
+    def __init__(self, cfg=None):
+        super().__init__(flow_spec())
+        self.cfg = cfg
+        self._pk = None
+        self._const = {}
+        self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
+
+    def _invalidate(self):
+        self._pk = None
+        self._const = {}
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    # ================================================================== weight prepack
+    def pack(self):
+        p = flat_params(self)
+        pk = {}
+
+        def lin(name):
+            return p[name + ".weight"].contiguous(), p[name + ".bias"].contiguous()
+
+        def cat_lin(names):
+            return (torch.cat([p[n + ".weight"] for n in names], 0).contiguous(),
+                    torch.cat([p[n + ".bias"] for n in names], 0).contiguous())
+
+        def conv(name, cin_pad=None):
+            b = p.get(name + ".bias")
+            return pack_conv(p[name + ".weight"], cin_pad), (b.contiguous() if b is not None else None)
+
+        def twins(prefix):
+            t = {}
+            t["pe0"] = conv(prefix + "patch_embeds.0.proj", 4)
+            t["pe1"] = conv(prefix + "patch_embeds.1.proj")
+            for s in range(2):
+                t[f"pen{s}"] = lin(prefix + f"patch_embeds.{s}.norm")
+                b0, b1 = prefix + f"blocks.{s}.0.", prefix + f"blocks.{s}.1."
+                C = p[b0 + "norm1.weight"].shape[0]
+                qkv_w, qkv_b = lin(b0 + "attn.qkv")
+                t[f"l{s}"] = dict(n1=lin(b0 + "norm1"), qkv=(qkv_w, qkv_b), proj=lin(b0 + "attn.proj"), n2=lin(b0 + "norm2"),
+                                  fc1=lin(b0 + "mlp.fc1"), fc2=lin(b0 + "mlp.fc2"),
+                                  # a zero-padded token's q/k/v is the bias (twins.py:606-611)
+                                  pads=tuple(qkv_b[i * C:(i + 1) * C].expand(49, C).contiguous() for i in range(3)))
+                w9 = p[prefix + f"pos_block.{s}.proj.0.weight"].reshape(C, 9).t().contiguous()
+                t[f"peg{s}"] = (w9, p[prefix + f"pos_block.{s}.proj.0.bias"].contiguous())
+                t[f"g{s}"] = dict(n1=lin(b1 + "norm1"), q=lin(b1 + "attn.q"), kv=lin(b1 + "attn.kv"), sr=conv(b1 + "attn.sr"),
+                                  srn=lin(b1 + "attn.norm"), proj=lin(b1 + "attn.proj"), n2=lin(b1 + "norm2"),
+                                  fc1=lin(b1 + "mlp.fc1"), fc2=lin(b1 + "mlp.fc2"))
+            return t
+
+        pk["fnet"] = twins("memory_encoder.feat_encoder.svt.")
+        pk["cnet"] = twins("context_encoder.svt.")
+        c = "memory_encoder.cost_perceiver_encoder."
+        pe = dict(c0=conv(c + "patch_embed.proj.0"), c2=conv(c + "patch_embed.proj.2"), c4=conv(c + "patch_embed.proj.4"),
+                  f0=conv(c + "patch_embed.ffn_with_coord.0"), f2=conv(c + "patch_embed.ffn_with_coord.2"),
+                  norm=lin(c + "patch_embed.norm"))
+        pk["pe"] = pe
+        pk["latents"] = p[c + "latent_tokens"][0].contiguous()
+
+        def attn_layer(name, fuse_qkv):
+            d = dict(n1=lin(name + ".norm1"), n2=lin(name + ".norm2"), proj=lin(name + ".proj"), f0=lin(name + ".ffn.0"),
+                     f3=lin(name + ".ffn.3"), q=lin(name + ".q"))
+            if fuse_qkv:
+                d["qkv"] = cat_lin([name + ".q", name + ".k", name + ".v"])
+            d["kv"] = cat_lin([name + ".k", name + ".v"])
+            return d
+        pk["xin"] = attn_layer(c + "input_layer", False)
+        pk["self"] = [attn_layer(c + f"encoder_layers.{i}", True) for i in range(HP["encoder_depth"])]
+        vert = []
+        for i in range(HP["encoder_depth"]):
+            v = c + f"vertical_encoder_layers.{i}."
+            lb, gb = v + "local_block.", v + "global_block."
+            sk_w = p[gb + "attn.sr_key.weight"]           # [128, 192, 4, 4]: channels = [x(128) | ctx(64)]
+            vert.append(dict(
+                ln1=lin(lb + "norm1"), lctx=lin(lb + "attn.context_proj"), lq=lin(lb + "attn.q"), lk=lin(lb + "attn.k"),
+                lv=lin(lb + "attn.v"), lproj=lin(lb + "attn.proj"), ln2=lin(lb + "norm2"), lfc1=lin(lb + "mlp.fc1"),
+                lfc2=lin(lb + "mlp.fc2"),
+                gn1=lin(gb + "norm1"), gctx=lin(gb + "attn.context_proj"), gq=lin(gb + "attn.q"), gk=lin(gb + "attn.k"),
+                gv=lin(gb + "attn.v"), gproj=lin(gb + "attn.proj"), gn2=lin(gb + "norm2"), gfc1=lin(gb + "mlp.fc1"),
+                gfc2=lin(gb + "mlp.fc2"), gsrn=lin(gb + "attn.norm"),
+                gskx=pack_conv(sk_w[:, :128].contiguous()), gskc=pack_conv(sk_w[:, 128:].contiguous()),
+                gskb=p[gb + "attn.sr_key.bias"].contiguous(), gsv=conv(gb + "attn.sr_value")))
+        pk["vert"] = vert
+        m = "memory_decoder."
+        Q = HP["query_latent_dim"]
+        # local cost buffer layout: [cost_forward 81 | 3 zero | cost_global 64] (reference order is
+        # cat([cost_global, cost_forward]) decoder.py:319 -> permute convc1's input columns)
+        f0w = p[m + "flow_token_encoder.0.weight"].reshape(Q, 81)
+        f0 = torch.zeros((Q, 84), device=f0w.device)
+        f0[:, :81] = f0w
+        c1w = p[m + "update_block.encoder.convc1.weight"].reshape(256, 145)
+        c1 = torch.zeros((256, 148), device=c1w.device)
+        c1[:, :81] = c1w[:, 64:]
+        c1[:, 84:] = c1w[:, :64]
+        ub = m + "update_block."
+        pw, pb = p[m + "proj.weight"].reshape(256, 256).contiguous(), p[m + "proj.bias"].contiguous()
+        ca = m + "decoder_layer.cross_attend"
+        dec = dict(
+            fte0=(f0.contiguous(), p[m + "flow_token_encoder.0.bias"].contiguous()), fte2=conv(m + "flow_token_encoder.2"),
+            proj_net=(pw[:128].contiguous(), pb[:128].contiguous()), proj_inp=(pw[128:].contiguous(), pb[128:].contiguous()),
+            ca=attn_layer(ca, False), qk=pack_conv(p[m + "att.to_qk.weight"]),
+            convc1=(c1.contiguous(), p[ub + "encoder.convc1.bias"].contiguous()), convc2=conv(ub + "encoder.convc2"),
+            convf1=conv(ub + "encoder.convf1", 4), convf2=conv(ub + "encoder.convf2"), conv=conv(ub + "encoder.conv"),
+            to_v=pack_conv(p[ub + "aggregator.to_v.weight"]), gamma=p[ub + "aggregator.gamma"].contiguous(),
+            fh1=conv(ub + "flow_head.conv1"), fh2=conv(ub + "flow_head.conv2"), m0=conv(ub + "mask.0"))
+        m2w, m2b = conv(ub + "mask.2")
+        dec["m2"] = (m2w, (0.25 * m2b).contiguous())          # mask = .25 * conv (gru.py:333): alpha scales acc, bias pre-scaled
+        for gname in ("z1", "r1", "q1", "z2", "r2", "q2"):
+            dec[gname] = conv(ub + f"gru.conv{gname}")
+        pk["dec"] = dec
+        self._pk = pk
+        return pk
+
+    # ================================================================== shared blocks
+    @staticmethod
+    def _mlp(x, n2, fc1, fc2, eps, out=None):
+        dev = x.device
+        y = _new(x.shape[0], x.shape[1], dev)
+        ops.layernorm(x, n2[0], n2[1], y, eps)
+        h = _new(x.shape[0], fc1[0].shape[0], dev)
+        ops.conv_gemm(y, fc1[0], h, bias=fc1[1], act="gelu")
+        o = _new(x.shape[0], x.shape[1], dev) if out is None else out
+        ops.conv_gemm(h, fc2[0], o, bias=fc2[1], aux0=x)
+        return o
+
+    # ------------------------------------------------------------------ Twins-SVT-L stages 1-2
+    def _twins(self, t, x, B, H, W):
+        """encoders.py:21-40; x: prepped image rows [B*H*W, 4] -> feature rows [B*(H/8)*(W/8), 256]."""
+        dev = x.device
+        dims, heads, srs, patch = (128, 256), (4, 8), (8, 4), (4, 2)
+        for s in range(2):
+            C, hd, sr, ps = dims[s], heads[s], srs[s], patch[s]
+            H, W = H // ps, W // ps
+            N = B * H * W
+            e = _new(N, C, dev)
+            ops.conv_gemm(x, t[f"pe{s}"][0], e, geom=(B, H * ps, W * ps, ps, ps, ps, ps, 0, 0), bias=t[f"pe{s}"][1])
+            x = _new(N, C, dev)
+            ops.layernorm(e, t[f"pen{s}"][0], t[f"pen{s}"][1], x, 1e-5)
+            # ---- LSA block (twins.py:587-631)
+            L = t[f"l{s}"]
+            y = _new(N, C, dev)
+            ops.layernorm(x, L["n1"][0], L["n1"][1], y, 1e-6)
+            qkv = _new(N, 3 * C, dev)
+            ops.conv_gemm(y, L["qkv"][0], qkv, bias=L["qkv"][1])
+            att = _new(N, C, dev)
+            ops.window_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], H * W * 3 * C, 3 * C, *L["pads"], att,
+                                 H * W * C, C, B, H, W, hd, C // hd, 7, (C // hd) ** -0.5)
+            x1 = _new(N, C, dev)
+            ops.conv_gemm(att, L["proj"][0], x1, bias=L["proj"][1], aux0=x)
+            x2 = self._mlp(x1, L["n2"], L["fc1"], L["fc2"], 1e-6)
+            # ---- PEG (twins.py:793-808)
+            x3 = _new(N, C, dev)
+            ops.dwconv3x3_residual(x2, t[f"peg{s}"][0], t[f"peg{s}"][1], x3, B, H, W, C)
+            # ---- GSA block (twins.py:633-680)
+            Gk = t[f"g{s}"]
+            ops.layernorm(x3, Gk["n1"][0], Gk["n1"][1], y, 1e-6)
+            q = _new(N, C, dev)
+            ops.conv_gemm(y, Gk["q"][0], q, bias=Gk["q"][1])
+            Hk, Wk = H // sr, W // sr
+            Nk = Hk * Wk
+            xs = _new(B * Nk, C, dev)
+            ops.conv_gemm(y, Gk["sr"][0], xs, geom=(B, H, W, sr, sr, sr, sr, 0, 0), bias=Gk["sr"][1])
+            xsn = _new(B * Nk, C, dev)
+            ops.layernorm(xs, Gk["srn"][0], Gk["srn"][1], xsn, 1e-5)
+            kv = _new(B * Nk, 2 * C, dev)
+            ops.conv_gemm(xsn, Gk["kv"][0], kv, bias=Gk["kv"][1])
+            ops.attention_kvlds(q, (H * W * C, C), kv[:, :C], (Nk * 2 * C, 2 * C), kv[:, C:], (Nk * 2 * C, 2 * C), att,
+                                (H * W * C, C), B, hd, H * W, Nk, C // hd, (C // hd) ** -0.5)
+            x4 = _new(N, C, dev)
+            ops.conv_gemm(att, Gk["proj"][0], x4, bias=Gk["proj"][1], aux0=x3)
+            x = self._mlp(x4, Gk["n2"], Gk["fc1"], Gk["fc2"], 1e-6)
+        return x, H, W
+
+    # ------------------------------------------------------------------ cost-volume encoder
+    def _patch_embed(self, cost_maps, M, H2, W2):
+        """PatchEmbed.forward (encoder.py:60-95): cost maps [M, H2*W2] -> tokens [M*P, 128], P = H3*W3."""
+        pe = self._pk["pe"]
+        dev = cost_maps.device
+        Hp, Wp = (H2 + 7) // 8 * 8, (W2 + 7) // 8 * 8           # zero-pad to a multiple of the patch size (:63-66)
+        h, w = H2, W2
+        x = cost_maps.view(M * H2 * W2, 1)
+        for name, co in (("c0", 16), ("c2", 32), ("c4", 64)):
+            Hp, Wp = Hp // 2, Wp // 2
+            y = _new(M * Hp * Wp, co, dev)
+            ops.conv_gemm(x, pe[name][0], y, geom=(M, h, w, 6, 6, 2, 2, 2, 2, Hp, Wp), bias=pe[name][1],
+                          act="relu" if name != "c4" else "none")
+            x, h, w = y, Hp, Wp
+        P = h * w
+        key = ("pe_tab", h, w)
+        if key not in self._const:
+            # the 64 sine channels only depend on the patch position: fold ffn_with_coord.0's PE half
+            # into a per-position bias table  W[:, 64:] . pe(pos) + b   (encoder.py:77-88)
+            tab_in = _new(P, 64, dev)
+            ops.sine_pe(tab_in, 64, Wg=w, cscale=8.0, coff=4.0)
+            tab = _new(P, 128, dev)
+            ops.conv_gemm(tab_in, pe["f0"][0][:, 64:], tab, bias=pe["f0"][1])
+            self._const[key] = tab
+        f = _new(M * P, 128, dev)
+        ops.conv_gemm(x, pe["f0"][0][:, :64], f, aux0=self._const[key], row_mod=P, act="relu")
+        f2 = _new(M * P, 128, dev)
+        ops.conv_gemm(f, pe["f2"][0], f2, bias=pe["f2"][1])
+        ops.layernorm(f2, pe["norm"][0], pe["norm"][1], f, 1e-5)
+        return f, P
+
+    def _latent_layer(self, L, x, M, first, tokens=None, P=0):
+        """crossattentionlayer.py:37-56 (first=True: latents x patch tokens) / encoder.py:156-172."""
+        dev = x.device if x is not None else tokens.device
+        lat = self._pk["latents"]
+        nl = lat.shape[0]
+        if first:
+            qn = _new(nl, 128, dev)
+            ops.layernorm(lat, L["n1"][0], L["n1"][1], qn, 1e-5)
+            q = _new(nl, 128, dev)
+            ops.conv_gemm(qn, L["q"][0], q, bias=L["q"][1])
+            kv = _new(M * P, 256, dev)
+            ops.conv_gemm(tokens, L["kv"][0], kv, bias=L["kv"][1])
+            att = _new(M * nl, 128, dev)
+            ops.attention_small(q, (0, 128), kv[:, :128], (P * 256, 256), kv[:, 128:], (P * 256, 256), att, (nl * 128, 128),
+                                M, 8, nl, P, 16, 16 ** -0.5)
+            x1 = _new(M * nl, 128, dev)
+            ops.conv_gemm(att, L["proj"][0], x1, bias=L["proj"][1], aux0=lat, row_mod=nl)
+        else:
+            y = _new(M * nl, 128, dev)
+            ops.layernorm(x, L["n1"][0], L["n1"][1], y, 1e-5)
+            qkv = _new(M * nl, 384, dev)
+            ops.conv_gemm(y, L["qkv"][0], qkv, bias=L["qkv"][1])
+            att = _new(M * nl, 128, dev)
+            ops.attention_small(qkv[:, :128], (nl * 384, 384), qkv[:, 128:256], (nl * 384, 384), qkv[:, 256:], (nl * 384, 384),
+                                att, (nl * 128, 128), M, 8, nl, nl, 16, 16 ** -0.5)
+            x1 = _new(M * nl, 128, dev)
+            ops.conv_gemm(att, L["proj"][0], x1, bias=L["proj"][1], aux0=x)
+        return self._mlp_plain(x1, L)
+
+    @staticmethod
+    def _mlp_plain(x, L):
+        dev = x.device
+        y = _new(x.shape[0], x.shape[1], dev)
+        ops.layernorm(x, L["n2"][0], L["n2"][1], y, 1e-5)
+        h = _new(x.shape[0], L["f0"][0].shape[0], dev)
+        ops.conv_gemm(y, L["f0"][0], h, bias=L["f0"][1], act="gelu")
+        o = _new(x.shape[0], x.shape[1], dev)
+        ops.conv_gemm(h, L["f3"][0], o, bias=L["f3"][1], aux0=x)
+        return o
+
+    def _vertical(self, V, x, ctx, B, H1, W1, nl):
+        """VerticalSelfAttentionLayer (encoder.py:121-125): Block(LSA ws7) -> Block(GSA sr4) with context
+        (twins.py:253-304, 336-392, 787-790).  x rows are (b, pixel n, latent l) -> row (b*N + n)*nl + l."""
+        dev = x.device
+        N = H1 * W1
+        R = B * N * nl
+        C, Cc = 128, 64
+        Cq = C + Cc
+        # ---------------- local block
+        y = _new(R, C, dev)
+        ops.layernorm(x, V["ln1"][0], V["ln1"][1], y, 1e-5)
+        z = _new(B * N, Cq, dev, zero=True)
+        ops.conv_gemm(ctx, V["lctx"][0], z[:, C:], bias=V["lctx"][1])
+        ops.sine_pe(z, Cq, Wg=W1, ws=7, period=N, accumulate=True)          # window-local code (twins.py:285-288)
+        Tq, Tk = _new(B * N, C, dev), _new(B * N, C, dev)
+        ops.conv_gemm(z, V["lq"][0], Tq, bias=V["lq"][1])
+        ops.conv_gemm(z, V["lk"][0], Tk, bias=V["lk"][1])
+        q, k, v = _new(R, C, dev), _new(R, C, dev), _new(R, C, dev)
+        ops.conv_gemm(y, V["lq"][0][:, :C], q, aux0=Tq, row_div=nl)
+        ops.conv_gemm(y, V["lk"][0][:, :C], k, aux0=Tk, row_div=nl)
+        ops.conv_gemm(y, V["lv"][0], v, bias=V["lv"][1])
+        key = ("lsa_pad", id(V))
+        if key not in self._const:
+            zp = _new(49, Cq, dev, zero=True)                                 # zero token + window code
+            ops.sine_pe(zp, Cq, Wg=7, accumulate=True)
+            qp, kp = _new(49, C, dev), _new(49, C, dev)
+            ops.conv_gemm(zp, V["lq"][0], qp, bias=V["lq"][1])
+            ops.conv_gemm(zp, V["lk"][0], kp, bias=V["lk"][1])
+            self._const[key] = (qp, kp, V["lv"][1].expand(49, C).contiguous())
+        qp, kp, vp = self._const[key]
+        att = _new(R, C, dev)
+        for b in range(B):
+            sl = slice(b * N * nl, (b + 1) * N * nl)
+            ops.window_attention(q[sl], k[sl], v[sl], C, nl * C, qp, kp, vp, att[sl], C, nl * C, nl, H1, W1, 8, 16, 7, 16 ** -0.5)
+        x1 = _new(R, C, dev)
+        ops.conv_gemm(att, V["lproj"][0], x1, bias=V["lproj"][1], aux0=x)
+        x2 = self._mlp(x1, V["ln2"], V["lfc1"], V["lfc2"], 1e-5)
+        # ---------------- global block
+        ops.layernorm(x2, V["gn1"][0], V["gn1"][1], y, 1e-5)
+        z = _new(B * N, Cq, dev, zero=True)
+        ops.conv_gemm(ctx, V["gctx"][0], z[:, C:], bias=V["gctx"][1])
+        Hk, Wk = H1 // 4, W1 // 4
+        Nk = Hk * Wk
+        Tsk = _new(B * Nk, C, dev)                                           # sr_key over the context channels + bias
+        ops.conv_gemm(z[:, C:], V["gskc"], Tsk, geom=(B, H1, W1, 4, 4, 4, 4, 0, 0), bias=V["gskb"])
+        ops.sine_pe(z, Cq, Wg=W1, period=N, accumulate=True)                 # full-grid code on q (twins.py:358-361)
+        ops.conv_gemm(z, V["gq"][0], Tq, bias=V["gq"][1])
+        ops.conv_gemm(y, V["gq"][0][:, :C], q, aux0=Tq, row_div=nl)
+        key = ("gsa_kpe", id(V), Hk, Wk)
+        if key not in self._const:
+            pe_k = _new(Nk, C, dev)
+            ops.sine_pe(pe_k, C, Wg=Wk, cscale=4.0)                          # stride-4 code on k (twins.py:372-376)
+            tk = _new(Nk, C, dev)
+            ops.conv_gemm(pe_k, V["gk"][0], tk, bias=V["gk"][1])
+            self._const[key] = tk
+        Tkpe = self._const[key]
+        xk, xv = _new(B * nl * Nk, C, dev), _new(B * nl * Nk, C, dev)          # [b][l][Nk][C]
+        for b in range(B):
+            yb = y[b * N * nl:(b + 1) * N * nl]
+            for name, dst, extra in (("gskx", xk, dict(aux0=Tsk[b * Nk:(b + 1) * Nk], row_mod=Nk)),
+                                     ("gsv", xv, dict(bias=V["gsv"][1]))):
+                wgt = V[name] if name == "gskx" else V[name][0]
+                ops.conv_gemm(yb.view(N, nl * C)[:, :C], wgt, dst[b * nl * Nk:(b + 1) * nl * Nk][:Nk],
+                              geom=(1, H1, W1, 4, 4, 4, 4, 0, 0), batch=nl, bsa=C, bsw=0, bsc=Nk * C, **extra)
+        xkn, xvn = _new(B * nl * Nk, C, dev), _new(B * nl * Nk, C, dev)
+        ops.layernorm(xk, V["gsrn"][0], V["gsrn"][1], xkn, 1e-5)
+        ops.layernorm(xv, V["gsrn"][0], V["gsrn"][1], xvn, 1e-5)
+        kk, vv = _new(B * nl * Nk, C, dev), _new(B * nl * Nk, C, dev)
+        ops.conv_gemm(xkn, V["gk"][0], kk, aux0=Tkpe, row_mod=Nk)
+        ops.conv_gemm(xvn, V["gv"][0], vv, bias=V["gv"][1])
+        for b in range(B):
+            sl = slice(b * N * nl, (b + 1) * N * nl)
+            s2 = slice(b * nl * Nk, (b + 1) * nl * Nk)
+            ops.attention_kvlds(q[sl], (C, nl * C), kk[s2], (Nk * C, C), vv[s2], (Nk * C, C), att[sl], (C, nl * C), nl, 8, N, Nk,
+                                16, 16 ** -0.5)
+        x3 = _new(R, C, dev)
+        ops.conv_gemm(att, V["gproj"][0], x3, bias=V["gproj"][1], aux0=x2)
+        return self._mlp(x3, V["gn2"], V["gfc1"], V["gfc2"], 1e-5)
+
+    def _cost_encoder(self, cost_maps, ctx, B, H1, W1):
+        """CostPerceiverEncoder.forward (encoder.py:258-287) -> cost memory rows [B*N*8, 128]."""
+        pk = self._pk
+        M = B * H1 * W1
+        tokens, P = self._patch_embed(cost_maps, M, H1, W1)
+        x = self._latent_layer(pk["xin"], None, M, True, tokens, P)
+        short = x
+        nl = pk["latents"].shape[0]
+        for i in range(HP["encoder_depth"]):
+            x = self._latent_layer(pk["self"][i], x, M, False)
+            x = self._vertical(pk["vert"][i], x, ctx, B, H1, W1, nl)
+        # cost_encoder_res (encoder.py:281-282) adds the short-cut; the only consumer of the memory is the
+        # decoder's linear k/v projection, so the sum is folded there: kv(x + s) = kv(x) + kv(s).
+        return x, short
+
+    # ------------------------------------------------------------------ decoder
+    def _decoder(self, mem, mem_short, ctx, cost_maps, B, H1, W1, iters, trace=None):
+        """MemoryDecoder.forward eval branch (decoder.py:262-344)."""
+        D = self._pk["dec"]
+        dev = ctx.device
+        N = H1 * W1
+        R = B * N
+        nl = self._pk["latents"].shape[0]
+        hxA, hxB = _new(R, 512, dev), _new(R, 512, dev)          # [h | inp | motion | motion_global], [r*h | same]
+        ops.conv_gemm(ctx, D["proj_net"][0], hxA[:, :128], bias=D["proj_net"][1], act="tanh")
+        ops.conv_gemm(ctx, D["proj_inp"][0], hxA[:, 128:256], bias=D["proj_inp"][1], act="relu")
+        ops.copy2d(hxA[:, 128:256], hxB[:, 128:256])
+        # GMA attention, once (gma.py:54-76)
+        qk = _new(R, 256, dev)
+        ops.conv_gemm(hxA[:, 128:256], D["qk"], qk)
+        attn = torch.empty((B, N, N), device=dev)
+        ops.conv_gemm(qk[:N, :128], qk[:N, 128:], attn.view(B * N, N), alpha=128 ** -0.5, batch=B, bsa=N * 256,
+                      bsw=N * 256, bsc=N * N)
+        ops.softmax_rows(attn.view(B * N, N))
+        # k, v of the cost-memory cross attention, once (decoder.py:68-70); memory = x + short_cut (linear -> two GEMMs)
+        ca = D["ca"]
+        kv0 = _new(R * nl, 128, dev)
+        ops.conv_gemm(mem_short, ca["kv"][0], kv0, bias=ca["kv"][1])
+        kv = _new(R * nl, 128, dev)
+        ops.conv_gemm(mem, ca["kv"][0], kv, aux0=kv0)
+        coords1 = _new(R, 2, dev)
+        ops.coords_grid(coords1, B, H1, W1)
+        corr = _new(R, 148, dev, zero=True)
+        flow4 = _new(R, 4, dev)
+        t64a, t64b, t64c, t64d = (_new(R, 64, dev) for _ in range(4))
+        cor1, corflo, flo1 = _new(R, 256, dev), _new(R, 256, dev), _new(R, 128, dev)
+        vT = torch.empty((B, 128, N), device=dev)
+        zbuf, fh = _new(R, 128, dev), _new(R, 256, dev)
+        g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
+        for it in range(iters):
+            ops.cost_lookup(cost_maps, coords1, corr, R, H1, W1, 4)                                   # decoder.py:291
+            ops.conv_gemm(corr[:, :84], D["fte0"][0], t64a, bias=D["fte0"][1], act="gelu")            # :305
+            ops.conv_gemm(t64a, D["fte2"][0], t64b, bias=D["fte2"][1])                                # query
+            ops.layernorm(t64b, ca["n1"][0], ca["n1"][1], t64a, 1e-5)
+            ops.sine_pe(t64a, 64, coords=coords1, accumulate=True)                                    # :76,88
+            ops.conv_gemm(t64a, ca["q"][0], t64c, bias=ca["q"][1])
+            ops.attention_small(t64c, (64, 64), kv[:, :64], (nl * 128, 128), kv[:, 64:], (nl * 128, 128), t64a, (64, 64),
+                                R, 8, 1, nl, 8, 8 ** -0.5)
+            ops.conv_gemm(t64a, ca["proj"][0], t64c, bias=ca["proj"][1], aux0=t64b)                   # + short_cut
+            ops.layernorm(t64c, ca["n2"][0], ca["n2"][1], t64a, 1e-5)
+            ops.conv_gemm(t64a, ca["f0"][0], t64d, bias=ca["f0"][1], act="gelu")
+            ops.conv_gemm(t64d, ca["f3"][0], corr[:, 84:], bias=ca["f3"][1], aux0=t64c)               # cost_global
+            ops.flow_from_coords(coords1, flow4, hxA[:, 382:384], B, H1, W1)                          # :321, gru.py:254
+            # BasicMotionEncoder (gru.py:246-254)
+            ops.conv_gemm(corr, D["convc1"][0], cor1, bias=D["convc1"][1], act="relu")
+            ops.conv_gemm(cor1, D["convc2"][0], corflo[:, :192], geom=g3, bias=D["convc2"][1], act="relu")
+            ops.conv_gemm(flow4, D["convf1"][0], flo1, geom=(B, H1, W1, 7, 7, 1, 1, 3, 3), bias=D["convf1"][1], act="relu")
+            ops.conv_gemm(flo1, D["convf2"][0], corflo[:, 192:], geom=g3, bias=D["convf2"][1], act="relu")
+            ops.conv_gemm(corflo, D["conv"][0], hxA[:, 256:382], geom=g3, bias=D["conv"][1], act="relu")
+            # GMA aggregate (gma.py:102-115): v^T = Wv . mf^T, out = mf + gamma * attn @ v
+            for b in range(B):
+                rows = slice(b * N, (b + 1) * N)
+                ops.conv_gemm(D["to_v"], hxA[rows, 256:384], vT[b])
+                ops.conv_gemm(attn[b], vT[b], hxA[rows, 384:], epi="axpy", aux1=hxA[rows, 256:384], scale_ptr=D["gamma"])
+            ops.copy2d(hxA[:, 256:], hxB[:, 256:])
+            # SepConvGRU (gru.py:44-59): horizontal 1x5 then vertical 5x1
+            for sfx, (kh, kw, ph, pw) in (("1", (1, 5, 0, 2)), ("2", (5, 1, 2, 0))):
+                gg = (B, H1, W1, kh, kw, 1, 1, ph, pw)
+                ops.conv_gemm(hxA, D["z" + sfx][0], zbuf, geom=gg, bias=D["z" + sfx][1], act="sigmoid")
+                ops.conv_gemm(hxA, D["r" + sfx][0], hxB[:, :128], geom=gg, bias=D["r" + sfx][1], act="sigmoid", epi="mul",
+                              aux1=hxA[:, :128])
+                ops.conv_gemm(hxB, D["q" + sfx][0], hxA[:, :128], geom=gg, bias=D["q" + sfx][1], act="tanh", epi="gru",
+                              aux1=zbuf, aux2=hxA[:, :128])
+            # flow head (gru.py:5-13) and coords1 += delta_flow (decoder.py:329)
+            ops.conv_gemm(hxA[:, :128], D["fh1"][0], fh, geom=g3, bias=D["fh1"][1], act="relu")
+            ops.conv_gemm(fh, D["fh2"][0], coords1, geom=g3, bias=D["fh2"][1], epi="add", aux1=coords1)
+            if trace is not None:
+                trace.append(dict(coords1=coords1.clone(), net=hxA[:, :128].clone(), corr=corr.clone()))
+        # mask head + convex upsampling, last iteration only (gru.py:315-318,333; decoder.py:214-225)
+        ops.conv_gemm(hxA[:, :128], D["m0"][0], fh, geom=g3, bias=D["m0"][1], act="relu")
+        mask = _new(R, 576, dev)
+        ops.conv_gemm(fh, D["m2"][0], mask, bias=D["m2"][1], alpha=0.25)
+        flow_up = torch.empty((B, 2, 8 * H1, 8 * W1), device=dev)
+        ops.convex_upsample(coords1, mask, flow_up, B, H1, W1)
+        return flow_up, coords1
+
+    # ================================================================== forward
+    def flow_rows(self, image1, image2, iters=None, trace=None):
+        """images NCHW 0..255 -> (flow_up [B,2,H,W], coords1 rows [B*N,2], (B,H1,W1))."""
+        if not image1.is_cuda:
+            raise RuntimeError("FlowFormer runs on the MI355X HIP kernels only: move the module and inputs to cuda")
+        pk = self._pk or self.pack()
+        iters = HP["decoder_depth"] if iters is None else iters
+        B, _, H, W = image1.shape
+        if H % 32 or W % 32:
+            raise RuntimeError(f"input size {H}x{W} must be a multiple of 32 (reference runs both nets at 512x512)")
+        dev = image1.device
+        x = _new(2 * B * H * W, 4, dev)
+        ops.prep_image(image1.contiguous(), x[:B * H * W], 4, 2.0, 255.0, 1.0)        # transformer.py:53-54
+        ops.prep_image(image2.contiguous(), x[B * H * W:], 4, 2.0, 255.0, 1.0)
+        ctx, H1, W1 = self._twins(pk["cnet"], x[:B * H * W], B, H, W)                 # context = cnet(image1)
+        feats, _, _ = self._twins(pk["fnet"], x, 2 * B, H, W)                        # fnet(image1), fnet(image2)
+        N = H1 * W1
+        feats = feats.view(2, B, N, 256)
+        cost_maps = torch.empty((B * N, N), device=dev)                              # all-pairs volume (encoder.py:359-369)
+        ops.corr_volume(feats[0], feats[1], cost_maps.view(B, N, N))
+        mem, short = self._cost_encoder(cost_maps, ctx, B, H1, W1)
+        if trace is not None:
+            trace.append(dict(context=ctx, feats=feats, cost_maps=cost_maps, mem=mem, short=short))
+        flow_up, coords1 = self._decoder(mem, short, ctx, cost_maps, B, H1, W1, iters, trace)
+        return flow_up, coords1, (B, H1, W1)
+
+    def forward(self, image1, image2, mask=None, output=None, flow_init=None):
+        """Reference surface (transformer.py:47-65, eval): returns (flow_up, flow_lowres)."""
+        if flow_init is not None:
+            raise NotImplementedError("flow_init (warm start) is not on the stitching path")
+        flow_up, coords1, (B, H1, W1) = self.flow_rows(image1, image2)
+        flow4 = _new(B * H1 * W1, 4, flow_up.device)
+        ops.flow_from_coords(coords1, flow4, None, B, H1, W1)
+        low = flow4[:, :2].reshape(B, H1, W1, 2).permute(0, 3, 1, 2).contiguous()       # layout only (unused by the adapter)
+        return flow_up, low
+
+
+def build_flowformer(cfg=None):
+    """reference: core/FlowFormer/__init__.py:2-9 (only 'percostformer3' exists)."""
+    name = getattr(cfg, "transformer", "percostformer3") if cfg is not None else "percostformer3"
+    if name != "percostformer3":
+        raise ValueError(f"FlowFormer = {name} is not a valid optimizer!")
+    sub = cfg[name] if cfg is not None and hasattr(cfg, "__getitem__") and name in cfg else None
+    return FlowFormer(sub)

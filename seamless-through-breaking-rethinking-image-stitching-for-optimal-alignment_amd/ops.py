@@ -25,6 +25,13 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _pc(t):
+    """pointer to a tensor the kernel reads as dense row-major"""
+    if t is not None and not t.is_contiguous():
+        raise ValueError(f"contiguous tensor expected, got shape {tuple(t.shape)} strides {t.stride()}")
+    return _p(t)
+
+
 def _ld(t):
     """row stride of a 2-D row-major view (last dim contiguous)."""
     assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride())
@@ -44,9 +51,11 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
         B, H, W, kh, kw, sh, sw, ph, pw = 1, 1, rows, 1, 1, 1, 1, 0, 0
         Ho, Wo = 1, rows
     else:
-        B, H, W, kh, kw, sh, sw, ph, pw = geom
+        B, H, W, kh, kw, sh, sw, ph, pw = geom[:9]
         Ho = (H + 2 * ph - kh) // sh + 1
         Wo = (W + 2 * pw - kw) // sw + 1
+        if len(geom) == 11:            # explicit output size (asymmetric zero padding on the right/bottom)
+            Ho, Wo = geom[9], geom[10]
     d.a, d.w, d.c = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.aux0 = aux0.data_ptr() if aux0 is not None else None
@@ -102,9 +111,9 @@ def dwconv3x3_residual(x, w9c, bias, out, B, H, W, Cc):
     return out
 
 
-def sine_pe(out, dim, *, coords=None, Wg=0, ws=0, cscale=1.0, coff=0.0, accumulate=False):
+def sine_pe(out, dim, *, coords=None, Wg=0, ws=0, period=0, cscale=1.0, coff=0.0, accumulate=False):
     check(lib.st_sine_pe(_p(out), _ld(out), out.shape[0], dim, _p(coords), _ld(coords) if coords is not None else 0,
-                         Wg, ws, cscale, coff, int(accumulate), _stream()), "st_sine_pe")
+                         Wg, ws, period, cscale, coff, int(accumulate), _stream()), "st_sine_pe")
     return out
 
 
@@ -138,7 +147,7 @@ def copy2d(src, dst):
 
 def prep_image(src, dst, ldo, mul, div, sub):
     B, Cc, H, W = src.shape
-    check(lib.st_prep_image(_p(src), _p(dst), B, Cc, H, W, ldo, mul, div, sub, _stream()), "st_prep_image")
+    check(lib.st_prep_image(_pc(src), _p(dst), B, Cc, H, W, ldo, mul, div, sub, _stream()), "st_prep_image")
     return dst
 
 
@@ -164,12 +173,12 @@ def convex_upsample(coords1, mask, out, B, H, W):
 
 # ---- geometric stage (NCHW) ------------------------------------------------------------------
 def dlt4(src4x2, motion, H_out, B, mscale_x=1.0, mscale_y=1.0, div=1.0):
-    check(lib.st_dlt4(_p(src4x2), _p(motion), _p(H_out), B, mscale_x, mscale_y, div, _stream()), "st_dlt4")
+    check(lib.st_dlt4(_pc(src4x2), _pc(motion), _pc(H_out), B, mscale_x, mscale_y, div, _stream()), "st_dlt4")
     return H_out
 
 
 def mat3_sandwich(L, X, R, out, invert=False):
-    check(lib.st_mat3_sandwich(_p(L), _p(X), _p(R), _p(out), X.shape[0], int(invert), _stream()), "st_mat3_sandwich")
+    check(lib.st_mat3_sandwich(_pc(L), _pc(X), _pc(R), _pc(out), X.shape[0], int(invert), _stream()), "st_mat3_sandwich")
     return out
 
 
@@ -183,19 +192,19 @@ def homo_warp(U, theta, out_hw, n_ones=0, want_idx=False, want_out=True):
     oh, ow = int(out_hw[0]), int(out_hw[1])
     out = torch.empty((B, Cc + n_ones, oh, ow), device=theta.device, dtype=torch.float32) if want_out else None
     idx = torch.empty((B, oh, ow, 4), device=theta.device, dtype=torch.int32) if want_idx else None
-    check(lib.st_homo_warp(_p(U), _p(theta), _p(out), _p(idx), B, Cc, n_ones, H, W, oh, ow, _stream()), "st_homo_warp")
+    check(lib.st_homo_warp(_pc(U), _pc(theta), _p(out), _p(idx), B, Cc, n_ones, H, W, oh, ow, _stream()), "st_homo_warp")
     return (out, idx) if want_idx else out
 
 
 def mesh_bounds(H, out4, width, height, gw=511, gh=511):
-    check(lib.st_mesh_bounds(_p(H), _p(out4), H.shape[0], float(width), float(height), gw, gh, _stream()), "st_mesh_bounds")
+    check(lib.st_mesh_bounds(_pc(H), _p(out4), H.shape[0], float(width), float(height), gw, gh, _stream()), "st_mesh_bounds")
     return out4
 
 
 def flow_warp(x, flow, mul=None):
     B, Cc, H, W = x.shape
     out = torch.empty_like(x)
-    check(lib.st_flow_warp(_p(x), _p(flow), _p(mul), _p(out), B, Cc, H, W, _stream()), "st_flow_warp")
+    check(lib.st_flow_warp(_pc(x), _pc(flow), _pc(mul), _p(out), B, Cc, H, W, _stream()), "st_flow_warp")
     return out
 
 
@@ -203,7 +212,7 @@ def resize_bilinear(x, oh, ow, align_corners, div=None):
     B, Cc, H, W = x.shape
     out = torch.empty((B, Cc, oh, ow), device=x.device, dtype=torch.float32)
     d0, d1, nd = (div[0], div[1], 2) if div is not None else (1.0, 1.0, 0)
-    check(lib.st_resize_bilinear(_p(x), _p(out), B * Cc, H, W, oh, ow, int(align_corners), d0, d1, nd, _stream()),
+    check(lib.st_resize_bilinear(_pc(x), _p(out), B * Cc, H, W, oh, ow, int(align_corners), d0, d1, nd, _stream()),
           "st_resize_bilinear")
     return out
 
@@ -212,13 +221,13 @@ def range_map(flow):
     B, _, H, W = flow.shape
     scratch = torch.empty((B * H * W,), device=flow.device, dtype=torch.int64)
     out = torch.empty((B, 1, H, W), device=flow.device, dtype=torch.float32)
-    check(lib.st_range_map(_p(flow), _p(scratch), _p(out), B, H, W, _stream()), "st_range_map")
+    check(lib.st_range_map(_pc(flow), _p(scratch), _p(out), B, H, W, _stream()), "st_range_map")
     return out
 
 
 def occlusion_from_range(rng, threshold):
     out = torch.empty_like(rng)
-    check(lib.st_occlusion_from_range(_p(rng), _p(out), rng.numel(), int(threshold), _stream()), "st_occlusion_from_range")
+    check(lib.st_occlusion_from_range(_pc(rng), _p(out), rng.numel(), int(threshold), _stream()), "st_occlusion_from_range")
     return out
 
 
@@ -226,14 +235,14 @@ def morph_open(mask, ksz=19):
     B, Cc, H, W = mask.shape
     scratch = torch.empty((2 * B * Cc * H * W,), device=mask.device, dtype=torch.uint8)
     out = torch.empty_like(mask)
-    check(lib.st_morph_open(_p(mask), _p(out), _p(scratch), B * Cc, H, W, ksz, _stream()), "st_morph_open")
+    check(lib.st_morph_open(_pc(mask), _p(out), _p(scratch), B * Cc, H, W, ksz, _stream()), "st_morph_open")
     return out
 
 
 def eval_finish(final6, occ):
     B, _, H, W = final6.shape
     overlap = torch.empty((B, H, W), device=final6.device, dtype=torch.float32)
-    check(lib.st_eval_finish(_p(final6), _p(occ), _p(overlap), B, H, W, _stream()), "st_eval_finish")
+    check(lib.st_eval_finish(_pc(final6), _pc(occ), _p(overlap), B, H, W, _stream()), "st_eval_finish")
     return overlap
 
 
@@ -244,14 +253,14 @@ def blend(homo1, homo2, fin, occ):
     m1 = torch.empty((1, 3, h, w), device=dev)
     m2 = torch.empty((1, 3, h, w), device=dev)
     bl = torch.empty((1, 3, h, w), device=dev, dtype=torch.uint8)
-    check(lib.st_blend(_p(homo1), _p(homo2), _p(fin), _p(occ), _p(o2), _p(m1), _p(m2), _p(bl), h, w, _stream()), "st_blend")
+    check(lib.st_blend(_pc(homo1), _pc(homo2), _pc(fin), _pc(occ), _p(o2), _p(m1), _p(m2), _p(bl), h, w, _stream()), "st_blend")
     return o2, m1, m2, bl
 
 
 def mean_threshold(x, thr):
     B, Cc, H, W = x.shape
     out = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
-    check(lib.st_mean_threshold(_p(x), _p(out), B, Cc, H, W, thr, _stream()), "st_mean_threshold")
+    check(lib.st_mean_threshold(_pc(x), _p(out), B, Cc, H, W, thr, _stream()), "st_mean_threshold")
     return out
 
 

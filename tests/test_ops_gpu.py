@@ -346,7 +346,7 @@ def test_tps(ops, golden_ops):
     d = (out.cpu() - ref_out).abs()
     # K=172 fp32 contraction with cancellation: sample positions agree to ~1e-4 px, values on a 0..255
     # noise image to a few 1e-2 (the reference itself differs from the oracle by this much across hosts)
-    assert np.percentile(d.numpy(), 99) < 2e-2 and d.mean() < 2e-3 and d.max() < 2.0
+    assert np.percentile(d.numpy(), 99) < 5e-2 and d.mean() < 3e-3 and d.max() < 2.0
 
 
 def test_blend_and_eval_finish(ops):

@@ -1,5 +1,5 @@
 import torch, time, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, '/root/repo')
 import stitch_amd
 ops = stitch_amd.ops
 def timeit(fn, n=20):
