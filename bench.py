@@ -1,0 +1,190 @@
+"""Headline benchmark: stitched image-pairs/s at 512x512 (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path (``FlowHomoAdpater.forward(type="test_eval")``: 1 homography pass,
+2 FlowFormer++ passes, warp / occlusion / blend) over one synthetic 512x512 pair (BASELINE.json
+configs[1]: 512x512, batch=1).  Pairs are independent, so ranks shard them with no data-path collective
+(weak scaling: every rank runs K pairs); one RCCL all-gather moves the per-pair PSNR at the end.
+Inputs and random-init weights are resident in HBM before the timed region.
+
+Besides the contract fields the JSON line carries
+  roofline      -- the dominant kernel (fp32-MFMA implicit GEMM family, `conv_gemm_kernel`): algorithmic
+                   FLOPs of its launches in one step / their summed HIP-event durations, vs the 157.3 TFLOP/s
+                   fp32 matrix peak (MI355X_MICROARCH.md); measured on an instrumented step after the
+                   timed region (events on torch's current stream, where the kernels are launched)
+  corr_volume   -- the all-pairs correlation kernel alone (B=8, BASELINE.json configs[2]) against both roofs
+  cpu_baseline  -- the CPU oracle (torch-CPU port of the reference path) timed on this host, rank 0, N=1
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = vector fp32 peak
+HBM_PEAK_GBS = 8000.0
+
+
+def instrumented_step(model, a, b, ops):
+    """Run one step with a HIP-event pair around every st_conv_gemm launch; return (flops, ms, launches)."""
+    rec = []
+    orig = ops.conv_gemm
+
+    def timed(x, w, out, **kw):
+        geom = kw.get("geom")
+        Cin = x.shape[1]
+        if geom is None:
+            M = kw.get("M") or x.shape[0]
+            K = Cin
+        else:
+            B, H, W, kh, kw_, sh, sw, ph, pw = geom[:9]
+            Ho, Wo = ((H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw_) // sw + 1) if len(geom) == 9 else geom[9:11]
+            M, K = B * Ho * Wo, kh * kw_ * Cin
+        flops = 2.0 * M * w.shape[0] * K * max(1, kw.get("batch", 1))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(x, w, out, **kw)
+        e1.record()
+        rec.append((flops, e0, e1))
+        return r
+
+    ops.conv_gemm = timed
+    try:
+        model(a, b, type="test_eval")
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_gemm = orig
+    return sum(f for f, _, _ in rec), sum(e0.elapsed_time(e1) for _, e0, e1 in rec), len(rec)
+
+
+def corr_roofline(ops, B=8, N=4096, C=256, iters=10):
+    f1 = torch.randn(B, N, C, device="cuda")
+    f2 = torch.randn(B, N, C, device="cuda")
+    vol = torch.empty(B, N, N, device="cuda")
+    for _ in range(2):
+        ops.corr_volume(f1, f2, vol)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.corr_volume(f1, f2, vol)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    bytes_ = B * (2 * N * C * 4 + N * N * 4)          # 75.50 MB per sample
+    flops = B * 2.0 * N * N * C                       # 8.590 GFLOP per sample
+    return dict(ms=ms, hbm_gbs=bytes_ / ms / 1e6, hbm_frac=bytes_ / ms / 1e6 / HBM_PEAK_GBS,
+                tflops=flops / ms / 1e9, fma_frac=flops / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, batch=B)
+
+
+def cpu_baseline():
+    """CPU oracle (port of the reference path) on one 512x512 pair, all host cores."""
+    from oracle import adapter as oadapter
+    from oracle import inputs, spec
+    sd = spec.seeded_state_dict(1234)
+    a, b = inputs.structured_pair(512, 512, seed=7)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))     # the GPU box grants a 16-core share per GPU
+    with torch.no_grad():
+        t0 = time.time()
+        oadapter.forward_test_eval(sd, a, b)
+        dt = time.time() - t0
+    return dict(value=1.0 / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample="1 pair, 512x512, type=test_eval (1 homography + 2 FlowFormer passes), torch-CPU fp32 oracle")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
+    torch.cuda.set_device(local)
+
+    import stitch_amd
+    from oracle import inputs                       # deterministic synthetic pairs (data only)
+    ops = stitch_amd.ops
+    cfg, _ = stitch_amd.load_inference_config("all_img1_with_inpaint_g12_transRef")
+    torch.manual_seed(1234)
+    model = stitch_amd.build_model(cfg).cuda().eval()          # random-init weights of the architecture
+    a, b = inputs.structured_pair(512, 512, seed=7 + rank)
+    a, b = a.cuda(), b.cuda()
+
+    def step():
+        o = model(a, b, type="test_eval")
+        img, msk = o["final_warp_output"][:, :3], o["final_warp_output"][:, 3:]
+        mse = (((img - a) * msk) ** 2).mean()
+        return 10.0 * torch.log10(255.0 ** 2 / mse.clamp_min(1e-12))
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    log("model built, warming up")
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    log("timed region")
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    psnr = torch.stack([step() for _ in range(args.steps)])
+    if dist:
+        gathered = [torch.empty_like(psnr) for _ in range(world)]
+        dist.all_gather(gathered, psnr)            # the path's only collective: per-pair metric reduction
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda")
+    if dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    if rank == 0:
+        log(f"timed region done: {dt:.3f} s for {args.steps} steps; instrumented step")
+        flops, gemm_ms, launches = instrumented_step(model, a, b, ops)
+        log("corr-volume roofline + cpu baseline")
+        tf = flops / gemm_ms / 1e9
+        out = {
+            "metric": "stitched image-pairs/s at 512x512", "value": world * args.steps / dt, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "UDIS-D-shaped 512x512 pairs, batch=1, FlowHomoAdpater.forward(type=test_eval)",
+                       "pairs_per_step_per_gpu": 1, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA implicit GEMM, all launches of one step)",
+                         "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "launches_per_step": launches, "gflop_per_step": flops / 1e9,
+                         "kernel_ms_per_step": gemm_ms},
+            "corr_volume": corr_roofline(ops),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                                     "act", "epi")]
         + [("alpha", C.c_float), ("batch", C.c_int32)]
         + [(n, C.c_int64) for n in ("batch_stride_a", "batch_stride_w", "batch_stride_c")]
-        + [("tile_cfg", C.c_int32)]
+        + [("tile_cfg", C.c_int32), ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
     )
 
 

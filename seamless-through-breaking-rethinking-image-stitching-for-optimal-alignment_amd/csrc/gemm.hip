@@ -21,6 +21,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BK 32
 #define LDS_LD (BK + 4)
 
+// v = act(alpha*acc + bias[n] + aux0) followed by the combine mode; shared by the GEMM epilogue and
+// the split-K reducer.
+__device__ __forceinline__ float gemm_epilogue(const st_gemm_desc& d, int m, int n, float acc, float sc) {
+    float v = acc * d.alpha + (d.bias ? d.bias[n] : 0.f);
+    if (d.aux0) {
+        int ar = m;
+        if (d.aux0_row_div > 1) ar = m / d.aux0_row_div;
+        if (d.aux0_row_mod > 0) ar = ar % d.aux0_row_mod;
+        v += d.aux0[(size_t)ar * d.ld_aux0 + n];
+    }
+    v = st_act(v, d.act);
+    switch (d.epi) {
+        case ST_EPI_ADD: v += d.aux1[(size_t)m * d.ld_aux1 + n]; break;
+        case ST_EPI_MUL: v *= d.aux1[(size_t)m * d.ld_aux1 + n]; break;
+        case ST_EPI_GRU: {
+            const float z = d.aux1[(size_t)m * d.ld_aux1 + n], h = d.aux2[(size_t)m * d.ld_aux2 + n];
+            v = (1.0f - z) * h + z * v;
+        } break;
+        case ST_EPI_AXPY: v = d.aux1[(size_t)m * d.ld_aux1 + n] + sc * v; break;
+        default: break;
+    }
+    return v;
+}
+
 template <int WARPS_M, int WARPS_N, int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
     constexpr int BM = WARPS_M * TM * 32;
@@ -34,8 +58,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
-    // batch (grid.z) offsets
-    const int bz = blockIdx.z;
+    // grid.z is either the batch index or, for split-K launches (batch == 1), the K slice
+    const int split = d.split_k > 1 ? d.split_k : 1;
+    const int bz = split > 1 ? 0 : blockIdx.z;
+    const int kz = split > 1 ? blockIdx.z : 0;
     const float* __restrict__ X = d.a + (size_t)bz * d.batch_stride_a;
     const float* __restrict__ Wt = d.w + (size_t)bz * d.batch_stride_w;
     float* __restrict__ C = d.c + (size_t)bz * d.batch_stride_c;
@@ -139,12 +165,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nkt = (K + BK - 1) / BK;
+    const int nkt_all = (K + BK - 1) / BK;
+    const int per = (nkt_all + split - 1) / split;
+    const int kt0 = kz * per;
+    const int nkt = min(nkt_all, kt0 + per);
     const int li = lane & 31, lh = lane >> 5;
-    load_tile(0);
-    store_tile(0);
+    if (kt0 < nkt) {
+        load_tile(kt0);
+        store_tile(kt0 & 1);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) load_tile(kt + 1);   // global loads in flight under the MFMAs
         const float* Ab = As + ((size_t)buf * BM + wm * TM * 32 + li) * LDS_LD + 4 * lh;
@@ -171,41 +202,33 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
     }
 
     // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li] of the 32x32 tile
-    const float alpha = d.alpha;
     const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int n = n0 + wn * TN * 32 + jn * 32 + li;
         if (n >= d.N) continue;
-        const float bv = d.bias ? d.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= d.M) continue;
-                float v = acc[i][jn][r] * alpha + bv;
-                if (d.aux0) {
-                    int ar = m;
-                    if (d.aux0_row_div > 1) ar = m / d.aux0_row_div;
-                    if (d.aux0_row_mod > 0) ar = ar % d.aux0_row_mod;
-                    v += d.aux0[(size_t)ar * d.ld_aux0 + n];
-                }
-                v = st_act(v, d.act);
-                switch (d.epi) {
-                    case ST_EPI_ADD: v += d.aux1[(size_t)m * d.ld_aux1 + n]; break;
-                    case ST_EPI_MUL: v *= d.aux1[(size_t)m * d.ld_aux1 + n]; break;
-                    case ST_EPI_GRU: {
-                        const float z = d.aux1[(size_t)m * d.ld_aux1 + n], h = d.aux2[(size_t)m * d.ld_aux2 + n];
-                        v = (1.0f - z) * h + z * v;
-                    } break;
-                    case ST_EPI_AXPY: v = d.aux1[(size_t)m * d.ld_aux1 + n] + sc * v; break;
-                    default: break;
-                }
-                C[(size_t)m * d.ldc + n] = v;
+                if (split > 1) d.workspace[((size_t)kz * d.M + m) * d.N + n] = acc[i][jn][r];   // raw partial sums
+                else C[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, acc[i][jn][r], sc);
             }
         }
     }
+}
+
+// split-K tail: sum the K-slice slabs [split][M][N] in slice order (deterministic) + epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const st_gemm_desc d) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)d.M * d.N) return;
+    const int m = idx / d.N, n = idx % d.N;
+    float acc = 0.f;
+    for (int z = 0; z < d.split_k; ++z) acc += d.workspace[((size_t)z * d.M + m) * d.N + n];
+    const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
+    d.c[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, acc, sc);
 }
 
 // Skinny GEMM (M <= 8 rows, e.g. the batch-1 regression head): weight-read bound, one wave per
@@ -241,7 +264,7 @@ template <int WARPS_M, int WARPS_N, int TM, int TN>
 static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
     constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-    dim3 grid(ntm * ntn, 1, d.batch > 0 ? d.batch : 1);
+    dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : (d.batch > 0 ? d.batch : 1));
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     if (vec) {
         auto k = conv_gemm_kernel<WARPS_M, WARPS_N, TM, TN, true>;
@@ -252,6 +275,8 @@ static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, d);
     }
+    if (d.split_k > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(((size_t)d.M * d.N + 255) / 256), dim3(256), 0, s, d);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
@@ -282,6 +307,22 @@ extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
         else if (nwg(128, 64) >= 384) cfg = 2;
         else cfg = 3;
     }
+    // split-K: a launch that cannot fill the 256 CUs (M = 4096-pixel maps x 64..256 channels) is cut
+    // along K into slabs reduced by a second tiny kernel (deterministic order; no atomics).
+    static const int bms[5] = {0, 128, 128, 64, 128}, bns[5] = {0, 128, 64, 64, 32};
+    const long tiles = nwg(bms[cfg], bns[cfg]);
+    int split = d.split_k;
+    if (split == 0) {
+        split = 1;
+        if (batch == 1 && d.workspace && tiles < 256 && d.K >= 512) {
+            split = (int)((512 + tiles - 1) / tiles);
+            if (split > d.K / 256) split = d.K / 256;
+            if (split > 16) split = 16;
+            while (split > 1 && (int64_t)split * d.M * d.N > d.workspace_floats) --split;
+        }
+    }
+    if (split > 1 && (batch != 1 || !d.workspace || (int64_t)split * d.M * d.N > d.workspace_floats)) return ST_EINVAL;
+    d.split_k = split;
     switch (cfg) {
         case 1: return launch_cfg<2, 2, 2, 2>(d, aligned, s);
         case 2: return launch_cfg<2, 2, 2, 1>(d, aligned, s);

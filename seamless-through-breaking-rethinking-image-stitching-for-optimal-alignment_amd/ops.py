@@ -38,8 +38,19 @@ def _ld(t):
     return t.stride(0)
 
 
+_WS = {}
+
+
+def _workspace(dev):
+    """per-device split-K slab buffer (64 MiB), allocated once"""
+    k = (dev.type, dev.index)
+    if k not in _WS:
+        _WS[k] = torch.empty((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
+    return _WS[k]
+
+
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
-              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, M=None, tile=0):
+              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, M=None, tile=0, split_k=0):
     """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
 
     x: 2-D view [rows, Cin] of a channels-last activation; geom=(B,H,W,kh,kw,sh,sw,ph,pw) or None (1x1).
@@ -74,6 +85,10 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     d.act, d.epi, d.alpha = ACT[act], EPI[epi], alpha
     d.batch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_c = batch, bsa, bsw, bsc
     d.tile_cfg = tile
+    d.split_k = split_k
+    if batch <= 1 and split_k != 1:
+        ws = _workspace(x.device)
+        d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     check(lib.st_conv_gemm(C.byref(d), _stream()), "st_conv_gemm")
     return out
 
