@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,8 +131,10 @@ def main():
     a, b = inputs.structured_pair(512, 512, seed=7 + rank)
     a, b = a.cuda(), b.cuda()
 
+    fwd = (lambda x, y: model(x, y, type="test_eval")) if args.eager else model.graphed("test_eval")
+
     def step():
-        o = model(a, b, type="test_eval")
+        o = fwd(a, b)
         img, msk = o["final_warp_output"][:, :3], o["final_warp_output"][:, 3:]
         mse = (((img - a) * msk) ** 2).mean()
         return 10.0 * torch.log10(255.0 ** 2 / mse.clamp_min(1e-12))
@@ -171,7 +174,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "UDIS-D-shaped 512x512 pairs, batch=1, FlowHomoAdpater.forward(type=test_eval)",
-                       "pairs_per_step_per_gpu": 1, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
+                       "pairs_per_step_per_gpu": 1, "launch": "eager" if args.eager else "hipGraph replay", "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA implicit GEMM, all launches of one step)",
                          "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": None, "launches_per_step": launches, "gflop_per_step": flops / 1e9,

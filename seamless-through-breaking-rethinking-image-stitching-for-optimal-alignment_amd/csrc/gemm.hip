@@ -302,9 +302,12 @@ extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
     auto nwg = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };
     int cfg = d.tile_cfg;
     if (cfg == 0) {
+        // measured on MI355X (tools/tile_sweep.py): the 64x64 tile wins for every short-K / mid-size shape of
+        // this path (more resident workgroups hide the load->LDS->MFMA latency); the 128-wide tiles only pay
+        // once K is long and the grid still covers the chip several times over.
         if (d.N <= 32) cfg = 4;
-        else if (d.N > 64 && nwg(128, 128) >= 384) cfg = 1;
-        else if (nwg(128, 64) >= 384) cfg = 2;
+        else if (d.K >= 1024 && d.N > 64 && nwg(128, 128) >= 1024) cfg = 1;
+        else if (d.K >= 1024 && nwg(128, 64) >= 1024) cfg = 2;
         else cfg = 3;
     }
     // split-K: a launch that cannot fill the 256 CUs (M = 4096-pixel maps x 64..256 channels) is cut

@@ -1,0 +1,60 @@
+"""Multi-GPU harness of the stitching path: one process per GPU, pairs sharded round-robin, no data-path
+collective; one all-gather (RCCL over xGMI on the GPU box, ``nccl`` backend) of the per-pair metrics at
+the end.  Replaces the reference's single-process ``nn.DataParallel`` (out.py:80, evaluate.py:119)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_pairs, rank, world):
+    """pair i goes to rank i % world (pairs are independent: no cross-sample op on the path)."""
+    return list(range(rank, n_pairs, world))
+
+
+def gather_metrics(local_idx, local_vals, n_pairs, device=None):
+    """All ranks contribute (index, values[k]) rows; every rank returns the full [n_pairs, k] table.
+
+    The only collective of the path (~16 B per pair): one all_gather of fixed-size padded blocks."""
+    vals = torch.as_tensor(local_vals, dtype=torch.float64).reshape(len(local_idx), -1)
+    k = vals.shape[1] if vals.numel() else 1
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        out = torch.full((n_pairs, k), float("nan"), dtype=torch.float64)
+        if len(local_idx):
+            out[torch.as_tensor(local_idx)] = vals
+        return out
+    world = dist.get_world_size()
+    cap = (n_pairs + world - 1) // world
+    dev = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    block = torch.full((cap, k + 1), float("nan"), dtype=torch.float64, device=dev)
+    if len(local_idx):
+        block[:len(local_idx), 0] = torch.as_tensor(local_idx, dtype=torch.float64, device=dev)
+        block[:len(local_idx), 1:] = vals.to(dev)
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(blocks, block)
+    out = torch.full((n_pairs, k), float("nan"), dtype=torch.float64)
+    for b in blocks:
+        b = b.cpu()
+        ok = ~torch.isnan(b[:, 0])
+        out[b[ok, 0].long()] = b[ok, 1:]
+    return out
+
+
+def split_easy_mid_hard(psnr_desc_sorted):
+    """evaluate.py:76-93: descending sort, slices [0:331], [331:663], [663:-1] (the worst pair is dropped)."""
+    s = psnr_desc_sorted
+    return s[0:331], s[331:663], s[663:-1]

@@ -1,0 +1,81 @@
+"""Host-side logic of the drop-in boundary on CPU (no GPU, no compute calls): checkpoint key set,
+config plugin surface, weight prepack layouts, loud failure without a GPU."""
+import json
+import os
+
+import pytest
+import torch
+
+import stitch_amd
+from oracle import spec
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_checkpoint_key_set_matches_reference():
+    want = json.load(open(os.path.join(GOLDEN, "state_keys.json")))
+    m = stitch_amd.build_model()
+    sd = m.state_dict()
+    assert set(sd) == set(want)
+    for k, (shape, dtype) in want.items():
+        assert list(sd[k].shape) == shape and str(sd[k].dtype).replace("torch.", "") == dtype, k
+    # product and oracle enumerate the same contract independently
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in spec.state_spec().items()}
+
+
+def test_strict_load_with_and_without_dataparallel_prefix(seeded_sd):
+    m = stitch_amd.build_model()
+    m.load_state_dict(seeded_sd, strict=True)
+    m.load_state_dict({"module." + k: v for k, v in seeded_sd.items()}, strict=True)
+    assert torch.equal(m.state_dict()["flow_backbone.memory_decoder.update_block.aggregator.gamma"], torch.tensor([0.5]))
+    bad = dict(seeded_sd)
+    bad.pop("homo_backbone.regressNet1_part2.4.bias")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+
+
+def test_config_plugin_surface():
+    for name in ("all_img1_with_inpaint_g12_transRef", "inpaint_all_area_g12_diffusion"):
+        cfg, tps = stitch_amd.load_inference_config(name)
+        assert cfg.transformer == "percostformer3" and cfg.percostformer3.decoder_depth == 12
+        assert cfg.test_not_use_combine_h_flow is True and cfg.use_fb_consistency_mask is True
+        assert cfg.use_forward is False and cfg.use_whole_resolution is False and cfg.pad_mode == "replicate"
+        assert hasattr(cfg, "use_foward") and not hasattr(cfg, "nonexistent_key")
+        assert (tps.grid_h, tps.grid_w) == (12, 12) and tps.tps_method == "opencv"
+    assert stitch_amd.load_inference_config("inpaint_all_area_g12_diffusion")[1].inpainter == "inpainter"
+    with pytest.raises(ModuleNotFoundError):
+        stitch_amd.load_inference_config("does_not_exist")
+
+
+def test_forward_type_dispatch_and_loud_cpu_failure(seeded_sd):
+    m = stitch_amd.build_model()
+    x = torch.zeros(1, 3, 512, 512)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, x, type="test_eval")
+    with pytest.raises(RuntimeError):
+        m.flow_backbone(x, x)
+    with pytest.raises(RuntimeError):
+        m.homo_backbone(x, x)
+
+
+def test_prepack_layouts(seeded_sd):
+    """BN folding and the (ky, kx, c) GEMM layout reproduce the conv they replace (CPU arithmetic only)."""
+    import torch.nn.functional as F
+    from stitch_amd.homography import fold_bn, pack_conv
+    p = {k[len("homo_backbone."):]: v for k, v in seeded_sd.items() if k.startswith("homo_backbone.")}
+    x = torch.randn(1, 3, 20, 24, generator=torch.Generator().manual_seed(0))
+    ref = F.batch_norm(F.conv2d(x, p["feature_extractor_stage1.0.weight"], stride=2, padding=3),
+                       p["feature_extractor_stage1.1.running_mean"], p["feature_extractor_stage1.1.running_var"],
+                       p["feature_extractor_stage1.1.weight"], p["feature_extractor_stage1.1.bias"], False, 0.0, 1e-5)
+    s, sh = fold_bn(p, "feature_extractor_stage1.1")
+    wp = pack_conv(p["feature_extractor_stage1.0.weight"], 4, s)                   # [64, 7*7*4]
+    cols = F.unfold(F.pad(x, (0, 0, 0, 0, 0, 1)), 7, padding=3, stride=2)          # [1, 4*49, L] (c, ky, kx)
+    cols = cols.view(1, 4, 49, -1).permute(0, 2, 1, 3).reshape(1, 196, -1)         # -> (ky, kx, c)
+    got = (wp @ cols[0] + sh[:, None]).view(1, 64, *ref.shape[2:])
+    assert (got - ref).abs().max() < 1e-4
+    m = stitch_amd.build_model()
+    m.load_state_dict(seeded_sd)
+    pk = m.flow_backbone.pack()
+    c1 = pk["dec"]["convc1"][0]
+    w = seeded_sd["flow_backbone.memory_decoder.update_block.encoder.convc1.weight"].reshape(256, 145)
+    assert torch.equal(c1[:, :81], w[:, 64:]) and torch.equal(c1[:, 84:], w[:, :64]) and (c1[:, 81:84] == 0).all()
