@@ -204,18 +204,19 @@ class GraphedForward:
         ent = self._graphs.get(key)
         if ent is None:
             a, b = input1_tensor.float().contiguous().clone(), input2_tensor.float().contiguous().clone()
+            ws = ops.new_workspace(a.device)            # this graph's own split-K slabs (graphs may replay concurrently)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), ops.workspace_scope(ws):
                 for _ in range(2):                      # warm-up: weight prepack, constant tables, LDS attributes
                     self.model(a, b, type=self.type)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph), ops.workspace_scope(ws):
                 out = self.model(a, b, type=self.type)
-            ent = self._graphs[key] = (graph, a, b, out)
-        graph, a, b, out = ent
+            ent = self._graphs[key] = (graph, a, b, out, ws)
+        graph, a, b, out = ent[:4]
         a.copy_(input1_tensor)
         b.copy_(input2_tensor)
         graph.replay()

@@ -39,14 +39,38 @@ def _ld(t):
 
 
 _WS = {}
+_WS_OVERRIDE = []
 
 
 def _workspace(dev):
-    """per-device split-K slab buffer (64 MiB), allocated once"""
-    k = (dev.type, dev.index)
+    """split-K slab buffer (64 MiB): one per (device, HIP stream) so concurrent streams never share
+    slabs; an execution context that is replayed on arbitrary streams (a captured hipGraph) brings its
+    own through ``workspace_scope``."""
+    if _WS_OVERRIDE:
+        return _WS_OVERRIDE[-1]
+    k = (dev.type, dev.index, torch.cuda.current_stream().cuda_stream)
     if k not in _WS:
-        _WS[k] = torch.empty((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
+        _WS[k] = new_workspace(dev)
     return _WS[k]
+
+
+def new_workspace(dev):
+    return torch.empty((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
+
+
+class workspace_scope:
+    """``with ops.workspace_scope(ws):`` -- every split-K GEMM launched inside uses ``ws``."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        _WS_OVERRIDE.append(self.ws)
+        return self.ws
+
+    def __exit__(self, *exc):
+        _WS_OVERRIDE.pop()
+        return False
 
 
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,

@@ -145,3 +145,20 @@ def test_end_to_end_test_out_256_vs_reference_golden(model):
         assert flips < 0.02 * o[key].numel(), (key, flips)
     assert o["residual_flow"].shape == (1, 2, 256, 256) and o["I_mat"].shape == (1, 3, 3)
     print(f"[e2e out] blend>2 frac {(d > 2).mean():.2e} mean abs {d.mean():.3f}")
+
+
+def test_graph_replay_and_concurrent_streams_match_eager(model):
+    """hipGraph replay (own split-K workspace per graph) == eager, also with 3 pairs in flight."""
+    pairs = [inputs.structured_pair(512, 512, seed=20 + i) for i in range(3)]
+    eager = [model(a.cuda(), b.cuda(), type="test_eval")["final_warp_output"].clone() for a, b in pairs]
+    graphs = [model.graphed("test_eval") for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for rep in range(2):
+        outs = []
+        for i, (a, b) in enumerate(pairs):
+            streams[i].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[i]):
+                outs.append(graphs[i](a.cuda(non_blocking=True), b.cuda(non_blocking=True))["final_warp_output"])
+        torch.cuda.synchronize()
+        for e, o in zip(eager, outs):
+            assert torch.equal(e, o)
