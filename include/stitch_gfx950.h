@@ -36,7 +36,8 @@ typedef struct st_gemm_desc {
     int32_t ldw, ldc, ld_aux0, ld_aux1, ld_aux2;
     int32_t aux0_row_div, aux0_row_mod;   /* 0/1 = identity row mapping                            */
     int32_t act;           /* 0 none, 1 relu, 2 gelu(erf), 3 sigmoid, 4 tanh                        */
-    int32_t epi;           /* 0 store, 1 +aux1, 2 *aux1, 3 GRU blend, 4 aux1 + *scale_ptr * v       */
+    int32_t epi;           /* 0 store, 1 +aux1, 2 *aux1, 3 GRU blend, 4 aux1 + *scale_ptr * v,
+                              5 z|r: cols<N/2 -> c, cols>=N/2 -> c2 = v*aux1                        */
     float alpha;           /* v = act(alpha*acc + bias + aux0)                                      */
     int32_t batch;         /* grid.z batches (0/1 = single)                                         */
     int64_t batch_stride_a, batch_stride_w, batch_stride_c;   /* in floats                          */
@@ -44,6 +45,9 @@ typedef struct st_gemm_desc {
     int32_t split_k;       /* 0 = auto, 1 = off, >1 = K slices (needs workspace, batch <= 1)        */
     float* workspace;      /* split-K slabs [split_k, M, N] or NULL (then never split)              */
     int64_t workspace_floats;
+    float* c2;             /* second output for epi 5 (fused GRU gates): [M, ldc2]                  */
+    int32_t ldc2;
+    uint32_t a_bytes, w_bytes;  /* filled by the library: extents of A / W for the buffer descriptors  */
 } st_gemm_desc;
 
 /* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.
@@ -98,6 +102,10 @@ int st_window_attention(const float* q, const float* k, const float* v, int64_t 
 /* CCL: 3x3 patch correlation + softmax(10 x) + soft-argmax (network.py:147-199) from the all-pairs
  * product G [B, P, P] of the normalised features; out [B, P, ldo] = (flow_w, flow_h, 0...).         */
 int st_ccl_softargmax(const float* G, float* out, int32_t ldo, int32_t B, int32_t h, int32_t w, void* stream);
+/* PatchEmbed's first conv, Conv2d(1,16,k6,s2,p2)+ReLU on single-channel cost maps (encoder.py:36-37);
+ * maps [M,H,W], w [36,16] (tap-major), out [M*Ho*Wo,16]; reads beyond H/W are zero (right/bottom pad). */
+int st_patch_conv1(const float* maps, const float* w36x16, const float* bias, float* out, int32_t M, int32_t H,
+                   int32_t W, int32_t Ho, int32_t Wo, void* stream);
 int st_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t rows, int32_t cols, void* stream);
 /* NCHW image -> channels-last rows with v = mul*(x/div) - sub (flowHomoAdpater.py:55-56,
  * transformer.py:53-54); channels C..ldo-1 are zero.                                               */

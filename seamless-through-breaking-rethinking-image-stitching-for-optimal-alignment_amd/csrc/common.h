@@ -20,7 +20,8 @@ enum {
     ST_EPI_ADD = 1,       // out = v + aux1                       (residual)
     ST_EPI_MUL = 2,       // out = v * aux1                       (GRU r*h)
     ST_EPI_GRU = 3,       // out = (1-aux1)*aux2 + aux1*v         (GRU state update, aux1=z, aux2=h)
-    ST_EPI_AXPY = 4       // out = aux1 + (*scale_ptr)*v          (GMA aggregate: fmap + gamma*out)
+    ST_EPI_AXPY = 4,      // out = aux1 + (*scale_ptr)*v          (GMA aggregate: fmap + gamma*out)
+    ST_EPI_ZR = 5         // cols < N/2: out = v ; cols >= N/2: c2 = v*aux1   (fused GRU z | r*h)
 };
 
 __device__ __forceinline__ float st_act(float v, int act) {

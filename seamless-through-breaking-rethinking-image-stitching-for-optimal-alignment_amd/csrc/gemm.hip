@@ -21,6 +21,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BK 32
 #define LDS_LD (BK + 4)
 
+// Operand tiles are fetched with raw buffer loads: a lane whose tap / row / k is out of range gets an
+// offset past the descriptor's num_records and the hardware returns zeros -- no branch and, crucially, no
+// select on the loaded data (a select makes the compiler wait for the load right after issuing it, which
+// serialises L2 latency with the MFMA block; measured: 3000 instead of ~1300 cycles per K step).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define ST_OOB 0x80000000u
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // v = act(alpha*acc + bias[n] + aux0) followed by the combine mode; shared by the GEMM epilogue and
 // the split-K reducer.
 __device__ __forceinline__ float gemm_epilogue(const st_gemm_desc& d, int m, int n, float acc, float sc) {
@@ -43,6 +55,21 @@ __device__ __forceinline__ float gemm_epilogue(const st_gemm_desc& d, int m, int
         default: break;
     }
     return v;
+}
+
+// epilogue + store.  ST_EPI_ZR (fused GRU gates, gru.py:47-49): columns [0, N/2) are z -> C,
+// columns [N/2, N) are r and leave as r*h -> c2 (aux1 = h).
+__device__ __forceinline__ void gemm_store(const st_gemm_desc& d, float* __restrict__ C, int m, int n, float acc, float sc) {
+    if (d.epi == ST_EPI_ZR) {
+        const int half = d.N >> 1;
+        float v = acc * d.alpha + (d.bias ? d.bias[n] : 0.f);
+        if (d.aux0) v += d.aux0[(size_t)m * d.ld_aux0 + n];
+        v = st_act(v, d.act);
+        if (n < half) C[(size_t)m * d.ldc + n] = v;
+        else d.c2[(size_t)m * d.ldc2 + (n - half)] = v * d.aux1[(size_t)m * d.ld_aux1 + (n - half)];
+        return;
+    }
+    C[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, acc, sc);
 }
 
 template <int WARPS_M, int WARPS_N, int TM, int TN, bool VEC>
@@ -98,26 +125,42 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
         } else { a_pix[p] = -1; a_b[p] = 0; a_iy0[p] = 0; a_ix0[p] = 0; }
     }
 
+    // descriptors over the whole A / W extents of this batch slice (wave-uniform: kernel args + blockIdx)
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)d.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, (int)d.w_bytes, 0x00020000);
     float4 ra[AP], rb[BP];
+    // VEC path state: this thread's (ky, kx, c) for the tile being loaded, advanced incrementally
+    // (one integer division per kernel instead of two per K step); loads are branch-free -- an
+    // out-of-range tap / row / k reads a safe address and is zeroed by a select, so the compiler
+    // can issue all of a step's global loads back to back.
+    int t_ky = 0, t_kx = 0, t_c = 0, t_kt = -2;   // -2: the first tile always decodes by division
     auto load_tile = [&](int kt) {
         const int k = kt * BK + kcol;
         if constexpr (VEC) {
-            int kyx = 0, c = k, ky = 0, kx = 0;
-            if (d.kh * d.kw > 1) { kyx = k / d.Cin; c = k - kyx * d.Cin; ky = kyx / d.kw; kx = kyx - ky * d.kw; }
+            if (d.kh * d.kw > 1) {
+                if (t_kt + 1 == kt && d.Cin >= BK) {
+                    t_c += BK;
+                    if (t_c >= d.Cin) { t_c -= d.Cin; if (++t_kx == d.kw) { t_kx = 0; ++t_ky; } }
+                } else {
+                    const int kyx = k / d.Cin;
+                    t_c = k - kyx * d.Cin; t_ky = kyx / d.kw; t_kx = kyx - t_ky * d.kw;
+                }
+                t_kt = kt;
+            } else { t_c = k; }
+            const bool kin = k < K;
 #pragma unroll
             for (int p = 0; p < AP; ++p) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int iy = a_iy0[p] + ky, ix = a_ix0[p] + kx;
-                if (a_pix[p] >= 0 && k < K && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
-                    v = *reinterpret_cast<const float4*>(X + ((size_t)(a_b[p] * d.H + iy) * d.W + ix) * d.ldx + c);
-                ra[p] = v;
+                const int iy = a_iy0[p] + t_ky, ix = a_ix0[p] + t_kx;
+                const bool ok = kin && a_pix[p] >= 0 && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+                const unsigned off = ok ? (unsigned)(((a_b[p] * d.H + iy) * d.W + ix) * d.ldx + t_c) * 4u : ST_OOB;
+                ra[p] = buf_load16(rsrcA, off);
             }
 #pragma unroll
             for (int p = 0; p < BP; ++p) {
                 const int n = n0 + rrow + 32 * p;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < d.N && k < K) v = *reinterpret_cast<const float4*>(Wt + (size_t)n * d.ldw + k);
-                rb[p] = v;
+                const bool ok = kin && n < d.N;
+                const unsigned off = ok ? (unsigned)(n * d.ldw + k) * 4u : ST_OOB;
+                rb[p] = buf_load16(rsrcW, off);
             }
         } else {
 #pragma unroll
@@ -214,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= d.M) continue;
                 if (split > 1) d.workspace[((size_t)kz * d.M + m) * d.N + n] = acc[i][jn][r];   // raw partial sums
-                else C[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, acc[i][jn][r], sc);
+                else gemm_store(d, C, m, n, acc[i][jn][r], sc);
             }
         }
     }
@@ -228,7 +271,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const st_gemm_desc d
     float acc = 0.f;
     for (int z = 0; z < d.split_k; ++z) acc += d.workspace[((size_t)z * d.M + m) * d.N + n];
     const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
-    d.c[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, acc, sc);
+    gemm_store(d, d.c, m, n, acc, sc);
 }
 
 // Skinny GEMM (M <= 8 rows, e.g. the batch-1 regression head): weight-read bound, one wave per
@@ -288,7 +331,16 @@ extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
     if (d.kh <= 0 || d.kw <= 0 || d.K != d.kh * d.kw * d.Cin) return ST_EINVAL;
     if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
+    if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    // byte extents of one batch slice of A and W for the buffer descriptors (must stay below 2 GiB so the
+    // out-of-range sentinel offset is always past num_records)
+    {
+        const int64_t a_rows = (int64_t)(d.M / (d.Ho * d.Wo)) * d.H * d.W;
+        const int64_t ab = ((a_rows - 1) * d.ldx + d.Cin) * 4, wb = ((int64_t)(d.N - 1) * d.ldw + d.K) * 4;
+        if (ab >= (int64_t)ST_OOB || wb >= (int64_t)ST_OOB) return ST_EINVAL;
+        d.a_bytes = (uint32_t)ab; d.w_bytes = (uint32_t)wb;
+    }
     const bool aligned = ((uintptr_t)d.a % 16 == 0) && ((uintptr_t)d.w % 16 == 0) && (d.ldx % 4 == 0) &&
                          (d.ldw % 4 == 0) && (d.Cin % 4 == 0) &&
                          (d.batch_stride_a % 4 == 0) && (d.batch_stride_w % 4 == 0);
@@ -306,9 +358,7 @@ extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
         // this path (more resident workgroups hide the load->LDS->MFMA latency); the 128-wide tiles only pay
         // once K is long and the grid still covers the chip several times over.
         if (d.N <= 32) cfg = 4;
-        else if (d.K >= 1024 && d.N > 64 && nwg(128, 128) >= 1024) cfg = 1;
-        else if (d.K >= 1024 && nwg(128, 64) >= 1024) cfg = 2;
-        else cfg = 3;
+        else cfg = 3;      // 1 (128x128) and 2 (128x64) stay selectable through tile_cfg
     }
     // split-K: a launch that cannot fill the 256 CUs (M = 4096-pixel maps x 64..256 channels) is cut
     // along K into slabs reduced by a second tiny kernel (deterministic order; no atomics).

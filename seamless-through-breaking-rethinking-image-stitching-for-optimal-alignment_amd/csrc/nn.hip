@@ -587,3 +587,49 @@ extern "C" int st_prep_image(const float* src, float* dst, int32_t B, int32_t C,
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// First PatchEmbed convolution (encoder.py:36 Conv2d(1, 16, k6, s2, p2) + ReLU) as a direct
+// kernel: the input has ONE channel (each row of the all-pairs volume is a cost map), so the
+// implicit-GEMM gather degenerates to scalar loads.  One thread = one output pixel x 16 channels;
+// the 36x16 weights are wave-uniform (scalar loads), the 16 outputs leave as four 16-B stores.
+// HBM-bound: 4 B read + 64 B written per output pixel.  maps [M, H, W]; w [36, 16]; out [M*Ho*Wo, 16].
+__global__ __launch_bounds__(256) void patch_conv1_kernel(const float* __restrict__ maps, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int M,
+                                                          int H, int W, int Ho, int Wo) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)M * Ho * Wo) return;
+    const int ox = idx % Wo;
+    const int oy = (idx / Wo) % Ho;
+    const size_t m = idx / ((size_t)Wo * Ho);
+    const float* im = maps + m * (size_t)H * W;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = bias[c];
+#pragma unroll
+    for (int ky = 0; ky < 6; ++ky) {
+        const int iy = oy * 2 - 2 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 6; ++kx) {
+            const int ix = ox * 2 - 2 + kx;
+            const float x = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? im[(size_t)iy * W + ix] : 0.f;
+            const float* wt = w + (ky * 6 + kx) * 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = fmaf(x, wt[c], acc[c]);
+        }
+    }
+    float4* o = reinterpret_cast<float4*>(out + idx * 16);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        o[c] = make_float4(fmaxf(acc[4 * c], 0.f), fmaxf(acc[4 * c + 1], 0.f), fmaxf(acc[4 * c + 2], 0.f), fmaxf(acc[4 * c + 3], 0.f));
+}
+
+extern "C" int st_patch_conv1(const float* maps, const float* w36x16, const float* bias, float* out, int32_t M, int32_t H,
+                              int32_t W, int32_t Ho, int32_t Wo, void* stream) {
+    if (!maps || !w36x16 || !bias || !out || M <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return ST_EINVAL;
+    const size_t total = (size_t)M * Ho * Wo;
+    hipLaunchKernelGGL(patch_conv1_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, maps, w36x16, bias, out,
+                       M, H, W, Ho, Wo);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

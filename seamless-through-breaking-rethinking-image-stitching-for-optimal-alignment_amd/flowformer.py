@@ -87,6 +87,7 @@ class FlowFormer(ParamTree):
         pe = dict(c0=conv(c + "patch_embed.proj.0"), c2=conv(c + "patch_embed.proj.2"), c4=conv(c + "patch_embed.proj.4"),
                   f0=conv(c + "patch_embed.ffn_with_coord.0"), f2=conv(c + "patch_embed.ffn_with_coord.2"),
                   norm=lin(c + "patch_embed.norm"))
+        pe["c0_direct"] = (p[c + "patch_embed.proj.0.weight"].reshape(16, 36).t().contiguous(), pe["c0"][1])
         pk["pe"] = pe
         pk["latents"] = p[c + "latent_tokens"][0].contiguous()
 
@@ -138,8 +139,19 @@ class FlowFormer(ParamTree):
             fh1=conv(ub + "flow_head.conv1"), fh2=conv(ub + "flow_head.conv2"), m0=conv(ub + "mask.0"))
         m2w, m2b = conv(ub + "mask.2")
         dec["m2"] = (m2w, (0.25 * m2b).contiguous())          # mask = .25 * conv (gru.py:333): alpha scales acc, bias pre-scaled
-        for gname in ("z1", "r1", "q1", "z2", "r2", "q2"):
-            dec[gname] = conv(ub + f"gru.conv{gname}")
+        # SepConvGRU (gru.py:32-59).  Input channels are [h | inp | motion | motion_global]; `inp` is constant
+        # over the 12 iterations, so its contribution (+ bias) becomes a per-pass table and the recurrent GEMMs
+        # contract over [h | motion | motion_global] only (K 2560 -> 1920).  z and r share their input: one GEMM.
+        for sfx in ("1", "2"):
+            parts = {}
+            for gate in ("z", "r", "q"):
+                wg = p[ub + f"gru.conv{gate}{sfx}.weight"]
+                parts[gate] = (pack_conv(torch.cat([wg[:, :128], wg[:, 256:]], 1).contiguous()),
+                               pack_conv(wg[:, 128:256].contiguous()), p[ub + f"gru.conv{gate}{sfx}.bias"])
+            dec["zr" + sfx] = torch.cat([parts["z"][0], parts["r"][0]], 0).contiguous()
+            dec["q" + sfx] = parts["q"][0]
+            dec["inp" + sfx] = (torch.cat([parts[g][1] for g in ("z", "r", "q")], 0).contiguous(),
+                                torch.cat([parts[g][2] for g in ("z", "r", "q")], 0).contiguous())
         pk["dec"] = dec
         self._pk = pk
         return pk
@@ -215,8 +227,11 @@ class FlowFormer(ParamTree):
         for name, co in (("c0", 16), ("c2", 32), ("c4", 64)):
             Hp, Wp = Hp // 2, Wp // 2
             y = _new(M * Hp * Wp, co, dev)
-            ops.conv_gemm(x, pe[name][0], y, geom=(M, h, w, 6, 6, 2, 2, 2, 2, Hp, Wp), bias=pe[name][1],
-                          act="relu" if name != "c4" else "none")
+            if name == "c0":
+                ops.patch_conv1(cost_maps, pe["c0_direct"][0], pe["c0_direct"][1], y, M, h, w, Hp, Wp)
+            else:
+                ops.conv_gemm(x, pe[name][0], y, geom=(M, h, w, 6, 6, 2, 2, 2, 2, Hp, Wp), bias=pe[name][1],
+                              act="relu" if name != "c4" else "none")
             x, h, w = y, Hp, Wp
         P = h * w
         key = ("pe_tab", h, w)
@@ -377,13 +392,19 @@ class FlowFormer(ParamTree):
         N = H1 * W1
         R = B * N
         nl = self._pk["latents"].shape[0]
-        hxA, hxB = _new(R, 512, dev), _new(R, 512, dev)          # [h | inp | motion | motion_global], [r*h | same]
+        hxA, hxB = _new(R, 384, dev), _new(R, 384, dev)          # [h | motion(126)+flow(2) | motion_global], [r*h | same]
+        inp = _new(R, 128, dev)
         ops.conv_gemm(ctx, D["proj_net"][0], hxA[:, :128], bias=D["proj_net"][1], act="tanh")
-        ops.conv_gemm(ctx, D["proj_inp"][0], hxA[:, 128:256], bias=D["proj_inp"][1], act="relu")
-        ops.copy2d(hxA[:, 128:256], hxB[:, 128:256])
+        ops.conv_gemm(ctx, D["proj_inp"][0], inp, bias=D["proj_inp"][1], act="relu")
+        # per-pass GRU tables: conv over the constant `inp` channels + bias, [z | r | q] for each half
+        gru_geom = {"1": (B, H1, W1, 1, 5, 1, 1, 0, 2), "2": (B, H1, W1, 5, 1, 1, 1, 2, 0)}
+        gru_tab = {}
+        for sfx in ("1", "2"):
+            gru_tab[sfx] = _new(R, 384, dev)
+            ops.conv_gemm(inp, D["inp" + sfx][0], gru_tab[sfx], geom=gru_geom[sfx], bias=D["inp" + sfx][1])
         # GMA attention, once (gma.py:54-76)
         qk = _new(R, 256, dev)
-        ops.conv_gemm(hxA[:, 128:256], D["qk"], qk)
+        ops.conv_gemm(inp, D["qk"], qk)
         attn = torch.empty((B, N, N), device=dev)
         ops.conv_gemm(qk[:N, :128], qk[:N, 128:], attn.view(B * N, N), alpha=128 ** -0.5, batch=B, bsa=N * 256,
                       bsw=N * 256, bsc=N * N)
@@ -416,27 +437,26 @@ class FlowFormer(ParamTree):
             ops.layernorm(t64c, ca["n2"][0], ca["n2"][1], t64a, 1e-5)
             ops.conv_gemm(t64a, ca["f0"][0], t64d, bias=ca["f0"][1], act="gelu")
             ops.conv_gemm(t64d, ca["f3"][0], corr[:, 84:], bias=ca["f3"][1], aux0=t64c)               # cost_global
-            ops.flow_from_coords(coords1, flow4, hxA[:, 382:384], B, H1, W1)                          # :321, gru.py:254
+            ops.flow_from_coords(coords1, flow4, hxA[:, 254:256], B, H1, W1)                          # :321, gru.py:254
             # BasicMotionEncoder (gru.py:246-254)
             ops.conv_gemm(corr, D["convc1"][0], cor1, bias=D["convc1"][1], act="relu")
             ops.conv_gemm(cor1, D["convc2"][0], corflo[:, :192], geom=g3, bias=D["convc2"][1], act="relu")
             ops.conv_gemm(flow4, D["convf1"][0], flo1, geom=(B, H1, W1, 7, 7, 1, 1, 3, 3), bias=D["convf1"][1], act="relu")
             ops.conv_gemm(flo1, D["convf2"][0], corflo[:, 192:], geom=g3, bias=D["convf2"][1], act="relu")
-            ops.conv_gemm(corflo, D["conv"][0], hxA[:, 256:382], geom=g3, bias=D["conv"][1], act="relu")
+            ops.conv_gemm(corflo, D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu")
             # GMA aggregate (gma.py:102-115): v^T = Wv . mf^T, out = mf + gamma * attn @ v
             for b in range(B):
                 rows = slice(b * N, (b + 1) * N)
-                ops.conv_gemm(D["to_v"], hxA[rows, 256:384], vT[b])
-                ops.conv_gemm(attn[b], vT[b], hxA[rows, 384:], epi="axpy", aux1=hxA[rows, 256:384], scale_ptr=D["gamma"])
-            ops.copy2d(hxA[:, 256:], hxB[:, 256:])
+                ops.conv_gemm(D["to_v"], hxA[rows, 128:256], vT[b])
+                ops.conv_gemm(attn[b], vT[b], hxA[rows, 256:], epi="axpy", aux1=hxA[rows, 128:256], scale_ptr=D["gamma"])
+            ops.copy2d(hxA[:, 128:], hxB[:, 128:])
             # SepConvGRU (gru.py:44-59): horizontal 1x5 then vertical 5x1
-            for sfx, (kh, kw, ph, pw) in (("1", (1, 5, 0, 2)), ("2", (5, 1, 2, 0))):
-                gg = (B, H1, W1, kh, kw, 1, 1, ph, pw)
-                ops.conv_gemm(hxA, D["z" + sfx][0], zbuf, geom=gg, bias=D["z" + sfx][1], act="sigmoid")
-                ops.conv_gemm(hxA, D["r" + sfx][0], hxB[:, :128], geom=gg, bias=D["r" + sfx][1], act="sigmoid", epi="mul",
-                              aux1=hxA[:, :128])
-                ops.conv_gemm(hxB, D["q" + sfx][0], hxA[:, :128], geom=gg, bias=D["q" + sfx][1], act="tanh", epi="gru",
-                              aux1=zbuf, aux2=hxA[:, :128])
+            for sfx in ("1", "2"):
+                gg, tab = gru_geom[sfx], gru_tab[sfx]
+                ops.conv_gemm(hxA, D["zr" + sfx], zbuf, geom=gg, aux0=tab[:, :256], act="sigmoid", epi="zr",
+                              aux1=hxA[:, :128], out2=hxB[:, :128])                                   # z ; r*h
+                ops.conv_gemm(hxB, D["q" + sfx], hxA[:, :128], geom=gg, aux0=tab[:, 256:], act="tanh", epi="gru",
+                              aux1=zbuf, aux2=hxA[:, :128])                                           # h = (1-z)h + z q
             # flow head (gru.py:5-13) and coords1 += delta_flow (decoder.py:329)
             ops.conv_gemm(hxA[:, :128], D["fh1"][0], fh, geom=g3, bias=D["fh1"][1], act="relu")
             ops.conv_gemm(fh, D["fh2"][0], coords1, geom=g3, bias=D["fh2"][1], epi="add", aux1=coords1)

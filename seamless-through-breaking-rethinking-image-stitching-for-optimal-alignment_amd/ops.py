@@ -9,7 +9,7 @@ import torch
 from ._lib import GemmDesc, check, lib
 
 ACT = dict(none=0, relu=1, gelu=2, sigmoid=3, tanh=4)
-EPI = dict(store=0, add=1, mul=2, gru=3, axpy=4)
+EPI = dict(store=0, add=1, mul=2, gru=3, axpy=4, zr=5)
 
 assert lib.st_abi_gemm_desc_size() == C.sizeof(GemmDesc), "st_gemm_desc ABI mismatch between header and binding"
 
@@ -74,7 +74,7 @@ class workspace_scope:
 
 
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
-              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, M=None, tile=0, split_k=0):
+              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, M=None, tile=0, split_k=0, out2=None):
     """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
 
     x: 2-D view [rows, Cin] of a channels-last activation; geom=(B,H,W,kh,kw,sh,sw,ph,pw) or None (1x1).
@@ -110,6 +110,8 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     d.batch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_c = batch, bsa, bsw, bsc
     d.tile_cfg = tile
     d.split_k = split_k
+    if out2 is not None:
+        d.c2, d.ldc2 = out2.data_ptr(), _ld(out2)
     if batch <= 1 and split_k != 1:
         ws = _workspace(x.device)
         d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
@@ -176,6 +178,11 @@ def window_attention(q, k, v, bs, ts, qpad, kpad, vpad, out, o_bs, o_ts, B, H, W
 
 def ccl_softargmax(G, out, B, h, w):
     check(lib.st_ccl_softargmax(_p(G), _p(out), _ld(out), B, h, w, _stream()), "st_ccl_softargmax")
+    return out
+
+
+def patch_conv1(maps, w36x16, bias, out, M, H, W, Ho, Wo):
+    check(lib.st_patch_conv1(_pc(maps), _pc(w36x16), _pc(bias), _p(out), M, H, W, Ho, Wo, _stream()), "st_patch_conv1")
     return out
 
 

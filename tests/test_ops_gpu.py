@@ -120,6 +120,28 @@ def test_conv_nhwc(ops, cfg):
     assert (from_rows(out, B, Ho, Wo) - ref).abs().max() < 2e-5
 
 
+def test_fused_gru_gates_epilogue(ops):
+    """epi='zr': one GEMM produces z (cols < N/2) and r*h (cols >= N/2) -- gru.py:47-49."""
+    M, K = 500, 96
+    a, w = torch.randn(M, K, generator=g(60)), torch.randn(256, K, generator=g(61)) / K ** 0.5
+    tab, h = torch.randn(M, 256, generator=g(62)), torch.randn(M, 128, generator=g(63))
+    pre = torch.sigmoid(F.linear(a, w) + tab)
+    z, rh = torch.empty(M, 128, device="cuda"), torch.empty(M, 130, device="cuda")
+    for split in (1, 3):
+        ops.conv_gemm(dev(a), dev(w), z, aux0=dev(tab), act="sigmoid", epi="zr", aux1=dev(h), out2=rh[:, 1:129], split_k=split)
+        assert (z.cpu() - pre[:, :128]).abs().max() < 1e-5
+        assert (rh[:, 1:129].cpu() - pre[:, 128:] * h).abs().max() < 1e-5
+
+
+def test_patch_conv1_direct(ops):
+    maps = torch.randn(5, 1, 12, 16, generator=g(64)) * 4
+    w, b = torch.randn(16, 1, 6, 6, generator=g(65)) / 6, torch.randn(16, generator=g(66))
+    ref = F.relu(F.conv2d(F.pad(maps, (0, 0, 0, 4)), w, b, stride=2, padding=2))          # H padded 12 -> 16
+    out = torch.empty(5 * 8 * 8, 16, device="cuda")
+    ops.patch_conv1(dev(maps.reshape(5, -1)), dev(w.reshape(16, 36).t()), dev(b), out, 5, 12, 16, 8, 8)
+    assert (from_rows(out, 5, 8, 8) - ref).abs().max() < 1e-5
+
+
 def test_corr_volume(ops):
     f1, f2 = torch.randn(2, 256, 16, 16, generator=g(13)), torch.randn(2, 256, 16, 16, generator=g(14))
     ref = nets.corr_volume(f1, f2)
