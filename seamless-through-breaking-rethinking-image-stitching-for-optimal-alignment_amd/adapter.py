@@ -73,6 +73,12 @@ class FlowHomoAdpater(nn.Module):
         """flow 1->2 at full resolution, eval: list of one tensor (flowHomoAdpater.py:63-70)."""
         return [self.flow_backbone.flow_rows(input1_tensor, input2_tensor)[0]]
 
+    def predict_flow_pair(self, input1_tensor, input2_tensor):
+        """(flow 1->2, flow 2->1) from one batched FlowFormer evaluation (see FlowFormer.flow_rows_pair)."""
+        B = input1_tensor.shape[0]
+        both = self.flow_backbone.flow_rows_pair(input1_tensor, input2_tensor)[0]
+        return both[:B], both[B:]
+
     def forward(self, input1_tensor, input2_tensor, type="train", pad_mode="constant", preprocess_callback=None):
         if not input1_tensor.is_cuda:
             raise RuntimeError("FlowHomoAdpater (gfx950) needs CUDA/HIP tensors: there is no CPU fallback")
@@ -106,12 +112,15 @@ class FlowHomoAdpater(nn.Module):
         output_H = ops.homo_warp(input2_tensor, H_mat.view(B, 9), (img_h, img_w), n_ones=3)            # :111
         output_H_inv = ops.homo_warp(input1_tensor, H_inv_mat.view(B, 9), (img_h, img_w), n_ones=3)    # :113
         warp2 = output_H[:, 0:3].contiguous()
-        flow_ij = self.predict_flow(input1_tensor, warp2)[0]                                           # :167
+        fb = _flag(self.cfg, "use_fb_consistency_mask", True)
+        if fb:
+            flow_ij, flow_ji = self.predict_flow_pair(input1_tensor, warp2)                            # :167 and :178, one batch
+        else:
+            flow_ij = self.predict_flow(input1_tensor, warp2)[0]                                       # :167
         final = ops.flow_warp(output_H, flow_ij)                                                       # :170
         out = dict()
-        if _flag(self.cfg, "use_fb_consistency_mask", True):
-            flow_ji = self.predict_flow(warp2, input1_tensor)[0]                                       # :178
-            occ = ops.occlusion_from_range(ops.range_map(flow_ji), True)                               # :180-181
+        if fb:
+            occ = ops.occlusion_from_range(ops.range_map(flow_ji.contiguous()), True)                  # :180-181
         else:
             occ = torch.ones((B, 1, img_h, img_w), device=dev)
         overlap = ops.eval_finish(final, occ)                                                          # :171-174,182
@@ -142,7 +151,7 @@ class FlowHomoAdpater(nn.Module):
         out_H = ops.homo_warp(b512, th.view(B, 9), (512, 512), n_ones=3)                               # :230
         warp2_512 = out_H[:, 0:3].contiguous()
         warp_mask_512 = ops.mean_threshold(out_H[:, 3:6].contiguous(), 0.5)                            # :233-234
-        flow512 = self.predict_flow(a512, warp2_512)[0]                                                # :236
+        flow512, back512 = self.predict_flow_pair(a512, warp2_512)                                     # :236 and :326, one batch
         residual = ops.resize_bilinear(flow512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))  # :241
         H = torch.empty((B, 3, 3), device=dev)
         ops.dlt4(self._corners(dev, float(img_w), float(img_h)), motion, H, B, img_w / 512.0, img_h / 512.0, 1.0)  # :244-253
@@ -169,7 +178,6 @@ class FlowHomoAdpater(nn.Module):
         final = ops.flow_warp(homo_output2, rf[:, 0:2].contiguous(), rf[:, 2:3].contiguous())          # :316-317
         if not _flag(self.cfg, "use_fb_consistency_mask", True):
             raise NotImplementedError("shipped inference config sets use_fb_consistency_mask=True")
-        back512 = self.predict_flow(warp2_512, a512)[0]                                                # :326
         back = ops.resize_bilinear(back512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))
         occ = ops.occlusion_from_range(ops.range_map(back), False)                                     # :332
         origin_occ = ops.morph_open(occ, 19)                                                           # :333-334

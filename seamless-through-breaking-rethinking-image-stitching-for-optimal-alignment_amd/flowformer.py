@@ -496,6 +496,36 @@ class FlowFormer(ParamTree):
         flow_up, coords1 = self._decoder(mem, short, ctx, cost_maps, B, H1, W1, iters, trace)
         return flow_up, coords1, (B, H1, W1)
 
+    def flow_rows_pair(self, image_a, image_b, iters=None):
+        """Both directions at once: returns flow_up [2B,2,H,W] = [flow a->b ; flow b->a].
+
+        The stitching path always needs the forward AND the backward flow of the same image pair
+        (flowHomoAdpater.py:167,178 / :236,326) and the two FlowFormer passes are independent, so they run
+        as one batch of 2B: the feature encoder sees each image once instead of twice (the reference
+        recomputes fnet(a), fnet(b) in the second pass), every GEMM of the encoder/decoder has twice the
+        rows (M = 8192 instead of 4096 per launch), and the launch count per pair halves."""
+        if not image_a.is_cuda:
+            raise RuntimeError("FlowFormer runs on the MI355X HIP kernels only: move the module and inputs to cuda")
+        pk = self._pk or self.pack()
+        iters = HP["decoder_depth"] if iters is None else iters
+        B, _, H, W = image_a.shape
+        if H % 32 or W % 32:
+            raise RuntimeError(f"input size {H}x{W} must be a multiple of 32 (reference runs both nets at 512x512)")
+        dev = image_a.device
+        x = _new(2 * B * H * W, 4, dev)
+        ops.prep_image(image_a.contiguous(), x[:B * H * W], 4, 2.0, 255.0, 1.0)
+        ops.prep_image(image_b.contiguous(), x[B * H * W:], 4, 2.0, 255.0, 1.0)
+        ctx, H1, W1 = self._twins(pk["cnet"], x, 2 * B, H, W)          # context of a (pass a->b) then of b (pass b->a)
+        feats, _, _ = self._twins(pk["fnet"], x, 2 * B, H, W)
+        N = H1 * W1
+        feats = feats.view(2, B, N, 256)
+        cost_maps = torch.empty((2 * B * N, N), device=dev)
+        ops.corr_volume(feats[0], feats[1], cost_maps[:B * N].view(B, N, N))
+        ops.corr_volume(feats[1], feats[0], cost_maps[B * N:].view(B, N, N))
+        mem, short = self._cost_encoder(cost_maps, ctx, 2 * B, H1, W1)
+        flow_up, coords1 = self._decoder(mem, short, ctx, cost_maps, 2 * B, H1, W1, iters)
+        return flow_up, coords1, (2 * B, H1, W1)
+
     def forward(self, image1, image2, mask=None, output=None, flow_init=None):
         """Reference surface (transformer.py:47-65, eval): returns (flow_up, flow_lowres)."""
         if flow_init is not None:
