@@ -177,6 +177,10 @@ def main():
         flops, gemm_ms, launches = instrumented_step(model, a, b, ops)
         log("corr-volume roofline + cpu baseline")
         tf = flops / gemm_ms / 1e9
+        traffic = None                  # HBM bytes per launch of the dominant kernel from the committed PMC passes
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         out = {
             "metric": "stitched image-pairs/s at 512x512", "value": world * args.steps / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -185,7 +189,8 @@ def main():
                        "pairs_per_step_per_gpu": 1, "launch": "eager" if args.eager else "hipGraph replay", "pairs_in_flight": nstreams, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA implicit GEMM, all launches of one step)",
                          "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "launches_per_step": launches, "gflop_per_step": flops / 1e9,
+                         "traffic": traffic, "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied)",
+                         "launches_per_step": launches, "gflop_per_step": flops / 1e9,
                          "kernel_ms_per_step": gemm_ms},
             "corr_volume": corr_roofline(ops),
         }
