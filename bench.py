@@ -116,12 +116,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "MASTER_PORT" in os.environ:      # launched by torch.distributed.run (also with 1 rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
-    torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world,      # "nccl" is RCCL on ROCm
+                                device_id=torch.device("cuda", local))
 
     import stitch_amd
     from oracle import inputs                       # deterministic synthetic pairs (data only)
