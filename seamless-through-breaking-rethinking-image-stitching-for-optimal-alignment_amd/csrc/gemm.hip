@@ -244,20 +244,92 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
         __syncthreads();
     }
 
-    // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li] of the 32x32 tile
+    // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li] of the 32x32 tile.  All mode switches are
+    // wave-uniform and sit OUTSIDE the 16-register loops, and the operand loads of a 16-row column are issued
+    // back to back from clamped rows (a per-element switch serialised 16 dependent L2 round trips: ~9 us per launch).
     const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
+    const int half = d.N >> 1;
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int n = n0 + wn * TN * 32 + jn * 32 + li;
-        if (n >= d.N) continue;
+        const bool ncol = n < d.N;
+        const int nc = ncol ? n : d.N - 1;
+        const float bv = d.bias ? d.bias[nc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * lh;
+            int mr[16];
+            bool ok[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= d.M) continue;
-                if (split > 1) d.workspace[((size_t)kz * d.M + m) * d.N + n] = acc[i][jn][r];   // raw partial sums
-                else gemm_store(d, C, m, n, acc[i][jn][r], sc);
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                ok[r] = ncol && m < d.M;
+                mr[r] = m < d.M ? m : d.M - 1;
+            }
+            if (split > 1) {                                   // raw partial sums -> slab
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok[r]) d.workspace[((size_t)kz * d.M + mr[r]) * d.N + n] = acc[i][jn][r];
+                continue;
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][jn][r] * d.alpha + bv;
+            if (d.aux0) {
+                float a0[16];
+                if (d.aux0_row_div > 1 || d.aux0_row_mod > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int ar = mr[r];
+                        if (d.aux0_row_div > 1) ar = ar / d.aux0_row_div;
+                        if (d.aux0_row_mod > 0) ar = ar % d.aux0_row_mod;
+                        a0[r] = d.aux0[(size_t)ar * d.ld_aux0 + nc];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a0[r] = d.aux0[(size_t)mr[r] * d.ld_aux0 + nc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += a0[r];
+            }
+            if (d.act != ST_ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = st_act(v[r], d.act);
+            }
+            if (d.epi == ST_EPI_STORE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = v[r];
+            } else if (d.epi == ST_EPI_ZR) {
+                if (nc < half) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = v[r];
+                } else {
+                    float h[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h[r] = d.aux1[(size_t)mr[r] * d.ld_aux1 + (nc - half)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (ok[r]) d.c2[(size_t)mr[r] * d.ldc2 + (n - half)] = v[r] * h[r];
+                }
+            } else {
+                float x1[16], x2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x1[r] = d.aux1[(size_t)mr[r] * d.ld_aux1 + nc];
+                if (d.epi == ST_EPI_GRU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x2[r] = d.aux2[(size_t)mr[r] * d.ld_aux2 + nc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float o = v[r];
+                    if (d.epi == ST_EPI_ADD) o = v[r] + x1[r];
+                    else if (d.epi == ST_EPI_MUL) o = v[r] * x1[r];
+                    else if (d.epi == ST_EPI_GRU) o = (1.0f - x1[r]) * x2[r] + x1[r] * v[r];
+                    else if (d.epi == ST_EPI_AXPY) o = x1[r] + sc * v[r];
+                    if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = o;
+                }
             }
         }
     }
