@@ -119,6 +119,13 @@ int st_flow_from_coords(const float* coords1, float* flow4, int32_t ld4, float* 
 /* encode_flow_token + bilinear_sampler (decoder.py:242-260, core/utils/utils.py:62-76).              */
 int st_cost_lookup(const float* maps, const float* coords, float* out, int32_t ldo, int32_t Nq, int32_t H2,
                    int32_t W2, int32_t r, void* stream);
+/* One fused launch for the row-local token chain of a refinement iteration: flow_token_encoder
+ * (decoder.py:148-152,305) + decoder CrossAttentionLayer (decoder.py:62-109: LN, sine PE of coords1, q, 8-head
+ * attention over the pixel's ntok<=8 memory tokens kv [rows*ntok,128]=(k|v), proj + short-cut, FFN).
+ * corr [rows, ld>=148]: reads cols 0..83 (cost_forward, 81 + 3 zero), writes cols 84..147 (cost_global).
+ * weights16 (host array of 16 device pointers): w0[64,84] b0 w2[64,64] b2 n1w n1b wq bq wp bp n2w n2b wf0 bf0 wf3 bf3. */
+int st_decoder_token_chain(float* corr, int32_t ld_corr, const float* coords1, const float* kv,
+                           const float* const* weights16, int32_t rows, int32_t ntok, void* stream);
 /* upsample_flow (decoder.py:214-225): mask [B*H*W, ldm>=576] -> out NCHW [B,2,8H,8W].              */
 int st_convex_upsample(const float* coords1, const float* mask, int32_t ldm, float* out, int32_t B, int32_t H,
                        int32_t W, void* stream);

@@ -135,3 +135,273 @@ extern "C" int st_convex_upsample(const float* coords1, const float* mask, int32
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Fused per-pixel token chain of one decoder refinement iteration (decoder.py:305-312 with
+// decoder.py:62-109 CrossAttentionLayer, flow_or_pe='and'):
+//   query = W2 . gelu(W0 . cost_forward + b0) + b2                       (flow_token_encoder)
+//   q     = Wq . (LN1(query) + sinePE(coords1)) + bq
+//   x     = query + Wp . MHA(q; k, v of the pixel's 8 cost-memory tokens) + bp     (8 heads x 8)
+//   out   = x + Wf3 . gelu(Wf0 . LN2(x) + bf0) + bf3                      -> cost_global
+// Every step is row-local with 64 channels, so one wave carries a 16-row tile through all six
+// 64-wide products on v_mfma_f32_16x16x4_f32 without leaving the CU: weights sit in LDS once per
+// workgroup, the tile bounces through a per-wave LDS slab only to turn the MFMA C layout back into
+// an A operand.  Replaces 11 launches per iteration (2 GEMM + LN + PE + GEMM + attention + GEMM +
+// LN + 2 GEMM) that were each latency-bound at M = 4096..8192 rows.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TC_LDW 68      // LDS row stride of a 64-wide weight / activation row (floats): conflict-free b128 reads
+#define TC_LDW0 100    // row stride for the 84(+12 zero)-wide first layer
+
+struct TokenChainArgs {
+    const float *w0, *b0, *w2, *b2, *n1w, *n1b, *wq, *bq, *wp, *bp, *n2w, *n2b, *wf0, *bf0, *wf3, *bf3;
+};
+
+// acc[t] (16x16 tile t of the 16x64 result, C layout) = X[16 x K] . W[64 x K]^T ; K multiple of 16
+template <int K, int LDX, int LDWT>
+__device__ __forceinline__ void tc_gemm(const float* __restrict__ X, const float* __restrict__ Wl, f32x4 acc[4], int lane) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < K / 16; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(X + i * LDX + 16 * j + 4 * g);
+        float4 b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const float4*>(Wl + (16 * t + i) * LDWT + 16 * j + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+    }
+}
+
+// C layout -> row-major LDS slab: lane (c = lane&15, g = lane>>4) holds rows 4g..4g+3 of column 16t+c
+__device__ __forceinline__ void tc_store(float* __restrict__ X, const f32x4 v[4], int lane) {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[(4 * g + r) * TC_LDW + 16 * t + c] = v[t][r];
+}
+
+__device__ __forceinline__ float sum16(float v) {     // across the 16 lanes that share lane>>4
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__device__ __forceinline__ void tc_layernorm(f32x4 v[4], const float* __restrict__ w, const float* __restrict__ b, int lane) {
+    const int c = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float mean = sum16((v[0][r] + v[1][r]) + (v[2][r] + v[3][r])) * (1.0f / 64.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const float dlt = v[t][r] - mean; q += dlt * dlt; }
+        const float rstd = 1.0f / sqrtf(sum16(q) * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t][r] = (v[t][r] - mean) * rstd * w[16 * t + c] + b[16 * t + c];
+    }
+}
+
+__global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restrict__ corr, int ldc, const float* __restrict__ coords1,
+                                                                  const float* __restrict__ kv, TokenChainArgs A, int rows, int ntok) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* W0 = sm;                                  // [64][TC_LDW0]
+    float* W2 = W0 + 64 * TC_LDW0;                   // five [64][TC_LDW]
+    float* Wq = W2 + 64 * TC_LDW;
+    float* Wp = Wq + 64 * TC_LDW;
+    float* Wf0 = Wp + 64 * TC_LDW;
+    float* Wf3 = Wf0 + 64 * TC_LDW;
+    float* Xall = Wf3 + 64 * TC_LDW;                 // 2 waves x [16][TC_LDW0]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = 128;                          // 2 waves per workgroup -> 256 workgroups at 8192 rows
+    // weights -> LDS: all of a matrix's 16-B loads are issued before the first LDS write (independent loads
+    // in flight together; a load->store loop serialised ~50 L2 round trips per workgroup)
+    {
+        float4 v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {               // first layer: 64 x 24 float4 (84 real columns = 21, zero up to 96)
+            const int e = tid + NT * i, n = e / 24, k4 = e % 24;
+            v[i] = k4 < 21 ? *reinterpret_cast<const float4*>(A.w0 + n * 84 + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int e = tid + NT * i, n = e / 24, k4 = e % 24;
+            *reinterpret_cast<float4*>(W0 + n * TC_LDW0 + 4 * k4) = v[i];
+        }
+        const float* src[5] = {A.w2, A.wq, A.wp, A.wf0, A.wf3};
+        float* dst[5] = {W2, Wq, Wp, Wf0, Wf3};
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(src[m] + 4 * (tid + NT * i));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid + NT * i, n = e >> 4, k4 = e & 15;
+                *reinterpret_cast<float4*>(dst[m] + n * TC_LDW + 4 * k4) = v[i];
+            }
+        }
+    }
+    float* X = Xall + wave * 16 * TC_LDW0;
+    const int row0 = (blockIdx.x * 2 + wave) * 16;
+    // stage this wave's 16 cost_forward rows (84 wide = 21 float4, zero padded to 96); corr rows are 16-B aligned
+    {
+        float4 v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = lane + 64 * i, r = e / 24, k4 = e % 24;
+            const int row = row0 + r;
+            v[i] = (row < rows && k4 < 21) ? *reinterpret_cast<const float4*>(corr + (size_t)row * ldc + 4 * k4)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = lane + 64 * i, r = e / 24, k4 = e % 24;
+            *reinterpret_cast<float4*>(X + r * TC_LDW0 + 4 * k4) = v[i];
+        }
+    }
+    __syncthreads();
+    const int c = lane & 15, g = lane >> 4;
+    f32x4 acc[4], query[4], x[4];
+    // ---- flow_token_encoder
+    tc_gemm<96, TC_LDW0, TC_LDW0>(X, W0, acc, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + A.b0[16 * t + c], ST_ACT_GELU);
+    __builtin_amdgcn_wave_barrier();
+    tc_store(X, acc, lane);
+    __builtin_amdgcn_wave_barrier();
+    tc_gemm<64, TC_LDW, TC_LDW>(X, W2, query, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) query[t][r] += A.b2[16 * t + c];
+    // ---- LN1 + sine PE of coords1 (tile t = sin x | cos x | sin y | cos y, band = c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = query[t];
+    tc_layernorm(acc, A.n1w, A.n1b, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = min(row0 + 4 * g + r, rows - 1);
+        const float px = coords1[(size_t)row * 2], py = coords1[(size_t)row * 2 + 1];
+        const float ax = ((3.14f * px) * (float)c) * 0.005f, ay = ((3.14f * py) * (float)c) * 0.005f;
+        acc[0][r] += sinf(ax); acc[1][r] += cosf(ax); acc[2][r] += sinf(ay); acc[3][r] += cosf(ay);
+    }
+    __builtin_amdgcn_wave_barrier();
+    tc_store(X, acc, lane);
+    __builtin_amdgcn_wave_barrier();
+    tc_gemm<64, TC_LDW, TC_LDW>(X, Wq, acc, lane);                       // q
+    // ---- 8-head attention over the pixel's ntok memory tokens (head = column / 8), in ROW layout: q goes back
+    // to the slab, then lane (row = lane&15, quarter = lane>>4) owns columns 16*quarter..+15 = two heads of its row
+    // and streams that slice of the row's k / v tokens with 16-B loads (no cross-lane traffic at all).
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += A.bq[16 * t + c];
+    __builtin_amdgcn_wave_barrier();
+    tc_store(X, acc, lane);
+    __builtin_amdgcn_wave_barrier();
+    {
+        const float scale = 0.35355339059327373f;                         // 8^-0.5
+        const int arow = lane & 15;
+        const int grow = min(row0 + arow, rows - 1);
+        const float* kvr = kv + (size_t)grow * ntok * 128 + 16 * g;
+        float qv[16], o[16];
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(X + arow * TC_LDW + 16 * g + e);
+            qv[e] = t4.x; qv[e + 1] = t4.y; qv[e + 2] = t4.z; qv[e + 3] = t4.w;
+        }
+        float s0[8], s1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a0 = 0.f, a1 = 0.f;
+            if (j < ntok) {
+                float kk[16];
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(kvr + j * 128 + e);
+                    kk[e] = t4.x; kk[e + 1] = t4.y; kk[e + 2] = t4.z; kk[e + 3] = t4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0 = fmaf(qv[e], kk[e], a0); a1 = fmaf(qv[8 + e], kk[8 + e], a1); }
+            }
+            s0[j] = j < ntok ? a0 * scale : -INFINITY;
+            s1[j] = j < ntok ? a1 * scale : -INFINITY;
+        }
+        float m0 = s0[0], m1 = s1[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) { m0 = fmaxf(m0, s0[j]); m1 = fmaxf(m1, s1[j]); }
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < ntok) {
+                const float p0 = expf(s0[j] - m0), p1 = expf(s1[j] - m1);
+                d0 += p0; d1 += p1;
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(kvr + j * 128 + 64 + e);
+                    const float pe = e < 8 ? p0 : p1;
+                    o[e] = fmaf(pe, t4.x, o[e]); o[e + 1] = fmaf(pe, t4.y, o[e + 1]);
+                    o[e + 2] = fmaf(pe, t4.z, o[e + 2]); o[e + 3] = fmaf(pe, t4.w, o[e + 3]);
+                }
+            }
+        }
+        const float i0 = 1.0f / d0, i1 = 1.0f / d1;
+#pragma unroll
+        for (int e = 0; e < 16; e += 4)
+            *reinterpret_cast<float4*>(X + arow * TC_LDW + 16 * g + e) =
+                make_float4(o[e] * (e < 8 ? i0 : i1), o[e + 1] * (e < 8 ? i0 : i1), o[e + 2] * (e < 8 ? i0 : i1), o[e + 3] * (e < 8 ? i0 : i1));
+    }
+    __builtin_amdgcn_wave_barrier();
+    tc_gemm<64, TC_LDW, TC_LDW>(X, Wp, acc, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[t][r] = query[t][r] + (acc[t][r] + A.bp[16 * t + c]);     // short_cut + proj
+    // ---- FFN
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = x[t];
+    tc_layernorm(acc, A.n2w, A.n2b, lane);
+    __builtin_amdgcn_wave_barrier();
+    tc_store(X, acc, lane);
+    __builtin_amdgcn_wave_barrier();
+    tc_gemm<64, TC_LDW, TC_LDW>(X, Wf0, acc, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + A.bf0[16 * t + c], ST_ACT_GELU);
+    __builtin_amdgcn_wave_barrier();
+    tc_store(X, acc, lane);
+    __builtin_amdgcn_wave_barrier();
+    tc_gemm<64, TC_LDW, TC_LDW>(X, Wf3, acc, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 4 * g + r;
+            if (row < rows) corr[(size_t)row * ldc + 84 + 16 * t + c] = x[t][r] + (acc[t][r] + A.bf3[16 * t + c]);
+        }
+}
+
+extern "C" int st_decoder_token_chain(float* corr, int32_t ld_corr, const float* coords1, const float* kv, const float* const* weights16,
+                                      int32_t rows, int32_t ntok, void* stream) {
+    if (!corr || !coords1 || !kv || !weights16 || rows <= 0 || ntok <= 0 || ntok > 8 || ld_corr < 148 || (ld_corr & 3)) return ST_EINVAL;
+    TokenChainArgs A;
+    const float** dst = reinterpret_cast<const float**>(&A);
+    for (int i = 0; i < 16; ++i) { if (!weights16[i]) return ST_EINVAL; dst[i] = weights16[i]; }
+    const size_t lds = (size_t)(64 * TC_LDW0 + 5 * 64 * TC_LDW + 2 * 16 * TC_LDW0) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)decoder_token_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(decoder_token_chain_kernel, dim3((rows + 31) / 32), dim3(128), lds, (hipStream_t)stream, corr, ld_corr, coords1, kv,
+                       A, rows, ntok);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

@@ -137,6 +137,10 @@ class FlowFormer(ParamTree):
             convf1=conv(ub + "encoder.convf1", 4), convf2=conv(ub + "encoder.convf2"), conv=conv(ub + "encoder.conv"),
             to_v=pack_conv(p[ub + "aggregator.to_v.weight"]), gamma=p[ub + "aggregator.gamma"].contiguous(),
             fh1=conv(ub + "flow_head.conv1"), fh2=conv(ub + "flow_head.conv2"), m0=conv(ub + "mask.0"))
+        cad = dec["ca"]
+        dec["chain16"] = [dec["fte0"][0], dec["fte0"][1], dec["fte2"][0], dec["fte2"][1], cad["n1"][0], cad["n1"][1],
+                          cad["q"][0], cad["q"][1], cad["proj"][0], cad["proj"][1], cad["n2"][0], cad["n2"][1],
+                          cad["f0"][0], cad["f0"][1], cad["f3"][0], cad["f3"][1]]
         m2w, m2b = conv(ub + "mask.2")
         dec["m2"] = (m2w, (0.25 * m2b).contiguous())          # mask = .25 * conv (gru.py:333): alpha scales acc, bias pre-scaled
         # SepConvGRU (gru.py:32-59).  Input channels are [h | inp | motion | motion_global]; `inp` is constant
@@ -419,24 +423,14 @@ class FlowFormer(ParamTree):
         ops.coords_grid(coords1, B, H1, W1)
         corr = _new(R, 148, dev, zero=True)
         flow4 = _new(R, 4, dev)
-        t64a, t64b, t64c, t64d = (_new(R, 64, dev) for _ in range(4))
         cor1, corflo, flo1 = _new(R, 256, dev), _new(R, 256, dev), _new(R, 128, dev)
         vT = torch.empty((B, 128, N), device=dev)
         zbuf, fh = _new(R, 128, dev), _new(R, 256, dev)
         g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
         for it in range(iters):
             ops.cost_lookup(cost_maps, coords1, corr, R, H1, W1, 4)                                   # decoder.py:291
-            ops.conv_gemm(corr[:, :84], D["fte0"][0], t64a, bias=D["fte0"][1], act="gelu")            # :305
-            ops.conv_gemm(t64a, D["fte2"][0], t64b, bias=D["fte2"][1])                                # query
-            ops.layernorm(t64b, ca["n1"][0], ca["n1"][1], t64a, 1e-5)
-            ops.sine_pe(t64a, 64, coords=coords1, accumulate=True)                                    # :76,88
-            ops.conv_gemm(t64a, ca["q"][0], t64c, bias=ca["q"][1])
-            ops.attention_small(t64c, (64, 64), kv[:, :64], (nl * 128, 128), kv[:, 64:], (nl * 128, 128), t64a, (64, 64),
-                                R, 8, 1, nl, 8, 8 ** -0.5)
-            ops.conv_gemm(t64a, ca["proj"][0], t64c, bias=ca["proj"][1], aux0=t64b)                   # + short_cut
-            ops.layernorm(t64c, ca["n2"][0], ca["n2"][1], t64a, 1e-5)
-            ops.conv_gemm(t64a, ca["f0"][0], t64d, bias=ca["f0"][1], act="gelu")
-            ops.conv_gemm(t64d, ca["f3"][0], corr[:, 84:], bias=ca["f3"][1], aux0=t64c)               # cost_global
+            # flow_token_encoder + cost-memory cross attention + FFN: one fused launch (decoder.py:305-312)
+            ops.decoder_token_chain(corr, coords1, kv, D["chain16"], R, nl)
             ops.flow_from_coords(coords1, flow4, hxA[:, 254:256], B, H1, W1)                          # :321, gru.py:254
             # BasicMotionEncoder (gru.py:246-254)
             ops.conv_gemm(corr, D["convc1"][0], cor1, bias=D["convc1"][1], act="relu")

@@ -212,6 +212,13 @@ def cost_lookup(maps, coords, out, Nq, H2, W2, r=4):
     return out
 
 
+def decoder_token_chain(corr, coords1, kv, weights16, rows, ntok):
+    """weights16: list of 16 contiguous device tensors (see include/stitch_gfx950.h)."""
+    arr = (C.c_void_p * 16)(*[w.data_ptr() for w in weights16])
+    check(lib.st_decoder_token_chain(_p(corr), _ld(corr), _pc(coords1), _p(kv), arr, rows, ntok, _stream()), "st_decoder_token_chain")
+    return corr
+
+
 def convex_upsample(coords1, mask, out, B, H, W):
     check(lib.st_convex_upsample(_p(coords1), _p(mask), _ld(mask), _p(out), B, H, W, _stream()), "st_convex_upsample")
     return out

@@ -417,3 +417,39 @@ def test_blend_and_eval_finish(ops):
     assert (fd.cpu() - fin6 * occ2).abs().max() == 0
     mt = ops.mean_threshold(dev(fin6[:, 3:6].contiguous()), 0.5)
     assert (mt.cpu() != (fin6[:, 3:6].mean(1, keepdim=True) > 0.5).float()).sum() <= 1
+
+
+def test_decoder_token_chain_fused(ops, seeded_sd):
+    """fused flow_token_encoder + decoder cross-attention layer vs the oracle's unfused chain (decoder.py:305-312)."""
+    R, nl = 300, 8
+    w = nets.W(seeded_sd, "flow_backbone.memory_decoder.")
+    ca = w.sub("decoder_layer.cross_attend.")
+    gg = g(70)
+    cf = torch.randn(1, 81, 15, 20, generator=gg) * 3                       # cost_forward [B,81,H1,W1]
+    coords = nets.coords_grid(1, 15, 20) + 2 * torch.randn(1, 2, 15, 20, generator=gg)
+    mem = torch.randn(R, nl, 128, generator=gg)
+    with torch.no_grad():
+        qy = nets.conv(w, "flow_token_encoder.2", F.gelu(nets.conv(w, "flow_token_encoder.0", cf)))
+        qy = qy.permute(0, 2, 3, 1).reshape(R, 1, 64)
+        k, v = nets.linear(ca, "k", mem), nets.linear(ca, "v", mem)
+        ref = nets.decoder_cross_attn(ca, qy, k, v, coords).reshape(R, 64)
+    sd = seeded_sd
+    p = "flow_backbone.memory_decoder."
+    c = p + "decoder_layer.cross_attend."
+    names = [(p + "flow_token_encoder.0.weight", (64, 81)), (p + "flow_token_encoder.0.bias", None),
+             (p + "flow_token_encoder.2.weight", (64, 64)), (p + "flow_token_encoder.2.bias", None),
+             (c + "norm1.weight", None), (c + "norm1.bias", None), (c + "q.weight", None), (c + "q.bias", None),
+             (c + "proj.weight", None), (c + "proj.bias", None), (c + "norm2.weight", None), (c + "norm2.bias", None),
+             (c + "ffn.0.weight", None), (c + "ffn.0.bias", None), (c + "ffn.3.weight", None), (c + "ffn.3.bias", None)]
+    ws = []
+    for name, shp in names:
+        t = sd[name].reshape(shp) if shp else sd[name]
+        if name.endswith("flow_token_encoder.0.weight"):
+            t = torch.cat([t, torch.zeros(64, 3)], 1)                            # 81 -> 84 zero-padded columns
+        ws.append(dev(t))
+    corr = torch.zeros(R, 148, device="cuda")
+    corr[:, :81] = dev(cf.permute(0, 2, 3, 1).reshape(R, 81))
+    kv = dev(torch.cat([k, v], -1).reshape(R * nl, 128))
+    ops.decoder_token_chain(corr, nhwc(coords), kv, ws, R, nl)
+    assert (corr[:, 84:].cpu() - ref).abs().max() < 1e-4, (corr[:, 84:].cpu() - ref).abs().max()
+    assert torch.equal(corr[:, :81].cpu(), cf.permute(0, 2, 3, 1).reshape(R, 81))
