@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
             const float4 t = *reinterpret_cast<const float4*>(kp + e);
             s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
         }
-        const float p = expf(s * scale - mx);
+        const float p = __expf(s * scale - mx);
         sum += p;
         const float* vp = vb + j * v_ts;
 #pragma unroll
@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void attention_kvlds_kernel(const float* __res
                                                               float* __restrict__ out, long o_bs, long o_ts, int Nq, int Nk,
                                                               float scale) {
     extern __shared__ __attribute__((aligned(16))) float kv[];   // [Nk][D] K then [Nk][D] V
+    constexpr int QPT = 2;                                        // queries per thread: each LDS broadcast feeds 2x the FMAs
     const int h = blockIdx.y, b = blockIdx.z;
     float* Ks = kv;
     float* Vs = kv + (size_t)Nk * D;
@@ -320,41 +321,85 @@ __global__ __launch_bounds__(256) void attention_kvlds_kernel(const float* __res
         *reinterpret_cast<float4*>(Vs + j * D + e) = *reinterpret_cast<const float4*>(v + b * v_bs + j * v_ts + h * D + e);
     }
     __syncthreads();
-    const int iq = blockIdx.x * 256 + threadIdx.x;
-    if (iq >= Nq) return;
-    float qr[D], acc[D];
-    const float* qp = q + b * q_bs + iq * q_ts + h * D;
+    const int iq0 = blockIdx.x * (256 * QPT) + threadIdx.x;      // this thread's queries: iq0, iq0 + 256
+    if (iq0 >= Nq) return;
+    float qr[QPT][D], acc[QPT][D], mx[QPT], sum[QPT];
+    bool live[QPT];
 #pragma unroll
-    for (int e = 0; e < D; e += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(qp + e);
-        qr[e] = t.x * scale; qr[e + 1] = t.y * scale; qr[e + 2] = t.z * scale; qr[e + 3] = t.w * scale;
-    }
-#pragma unroll
-    for (int e = 0; e < D; ++e) acc[e] = 0.f;
-    float mx = -INFINITY, sum = 0.f;
-    for (int j = 0; j < Nk; ++j) {
-        float s = 0.f;
+    for (int u = 0; u < QPT; ++u) {
+        const int iq = iq0 + 256 * u;
+        live[u] = iq < Nq;
+        const float* qp = q + b * q_bs + (long)(live[u] ? iq : iq0) * q_ts + h * D;
 #pragma unroll
         for (int e = 0; e < D; e += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(Ks + j * D + e);
-            s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
+            const float4 t = *reinterpret_cast<const float4*>(qp + e);
+            qr[u][e] = t.x * scale; qr[u][e + 1] = t.y * scale; qr[u][e + 2] = t.z * scale; qr[u][e + 3] = t.w * scale;
         }
-        const float nm = fmaxf(mx, s);
-        const float corr = expf(mx - nm), p = expf(s - nm);
-        mx = nm;
-        sum = sum * corr + p;
 #pragma unroll
-        for (int e = 0; e < D; e += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(Vs + j * D + e);
-            acc[e] = fmaf(p, t.x, acc[e] * corr); acc[e + 1] = fmaf(p, t.y, acc[e + 1] * corr);
-            acc[e + 2] = fmaf(p, t.z, acc[e + 2] * corr); acc[e + 3] = fmaf(p, t.w, acc[e + 3] * corr);
+        for (int e = 0; e < D; ++e) acc[u][e] = 0.f;
+        mx[u] = -INFINITY; sum[u] = 0.f;
+    }
+    // online softmax in chunks of 8 keys: one running-max update / accumulator rescale per chunk instead of per key
+    for (int j0 = 0; j0 < Nk; j0 += 8) {
+        float s[QPT][8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = j0 + jj;
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) s[u][jj] = 0.f;
+            if (j < Nk) {
+#pragma unroll
+                for (int e = 0; e < D; e += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(Ks + j * D + e);
+#pragma unroll
+                    for (int u = 0; u < QPT; ++u) {
+                        s[u][jj] = fmaf(qr[u][e], t.x, s[u][jj]); s[u][jj] = fmaf(qr[u][e + 1], t.y, s[u][jj]);
+                        s[u][jj] = fmaf(qr[u][e + 2], t.z, s[u][jj]); s[u][jj] = fmaf(qr[u][e + 3], t.w, s[u][jj]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < QPT; ++u) s[u][jj] = -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            float nm = mx[u];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) nm = fmaxf(nm, s[u][jj]);
+            const float corr = __expf(mx[u] - nm);
+            mx[u] = nm;
+            sum[u] *= corr;
+#pragma unroll
+            for (int e = 0; e < D; ++e) acc[u][e] *= corr;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) { s[u][jj] = __expf(s[u][jj] - nm); sum[u] += s[u][jj]; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = j0 + jj;
+            if (j < Nk) {
+#pragma unroll
+                for (int e = 0; e < D; e += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(Vs + j * D + e);
+#pragma unroll
+                    for (int u = 0; u < QPT; ++u) {
+                        acc[u][e] = fmaf(s[u][jj], t.x, acc[u][e]); acc[u][e + 1] = fmaf(s[u][jj], t.y, acc[u][e + 1]);
+                        acc[u][e + 2] = fmaf(s[u][jj], t.z, acc[u][e + 2]); acc[u][e + 3] = fmaf(s[u][jj], t.w, acc[u][e + 3]);
+                    }
+                }
+            }
         }
     }
-    const float inv = 1.0f / sum;
-    float* op = out + b * o_bs + iq * o_ts + h * D;
 #pragma unroll
-    for (int e = 0; e < D; e += 4)
-        *reinterpret_cast<float4*>(op + e) = make_float4(acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv);
+    for (int u = 0; u < QPT; ++u) {
+        if (!live[u]) continue;
+        const float inv = 1.0f / sum[u];
+        float* op = out + b * o_bs + (long)(iq0 + 256 * u) * o_ts + h * D;
+#pragma unroll
+        for (int e = 0; e < D; e += 4)
+            *reinterpret_cast<float4*>(op + e) = make_float4(acc[u][e] * inv, acc[u][e + 1] * inv, acc[u][e + 2] * inv, acc[u][e + 3] * inv);
+    }
 }
 
 extern "C" int st_attention_kvlds(const float* q, int64_t q_bs, int64_t q_ts, const float* k, int64_t k_bs, int64_t k_ts,
@@ -363,7 +408,7 @@ extern "C" int st_attention_kvlds(const float* q, int64_t q_bs, int64_t q_ts, co
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return ST_EINVAL;
     const size_t lds = (size_t)2 * Nk * D * sizeof(float);
     if (lds > 160 * 1024) return ST_EINVAL;
-    dim3 grid((Nq + 255) / 256, heads, B), block(256);
+    dim3 grid((Nq + 511) / 512, heads, B), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_AK(DD)                                                                                                   \
     do {                                                                                                                \
@@ -441,7 +486,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
             const float4 t = *reinterpret_cast<const float4*>(Ks + j * D + e);
             s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
         }
-        const float p = expf(s * scale - mx);
+        const float p = __expf(s * scale - mx);
         sum += p;
 #pragma unroll
         for (int e = 0; e < D; e += 4) {
