@@ -168,6 +168,17 @@ int st_tps_solve_grid(const float* U, const float* source, const float* target, 
                       float* out, int32_t* idx, int32_t B, int32_t C, int32_t H, int32_t W, int32_t N,
                       int32_t oh, int32_t ow, void* stream);
 
+/* ---- evaluation metric ------------------------------------------------------- */
+/* Masked PSNR / SSIM per image exactly as evaluate.py:53-65 feeds skimage 0.19.3 (uint8 truncation, mask =
+ * uint8(channel-mean mask), 7x7 uniform SSIM, K1=.01 K2=.03, sample covariance, 3-px crop, channel mean).
+ * image1 [B,3,H,W]; warped: B images of 3 planes, batch stride in floats (e.g. 6*H*W for final_warp_output);
+ * maskmean [B,H,W]; partial_f64: 2*B*ceil(3HW/256) doubles of scratch; out [B,2] fp64 = (psnr, ssim). */
+int st_masked_psnr_ssim(const float* image1, const float* warped, int64_t warped_batch_stride, const float* maskmean,
+                        void* partial_f64, double* out_psnr_ssim, int32_t B, int32_t H, int32_t W, void* stream);
+/* mean over C planes of x[b] (evaluate.py:45). */
+int st_channel_mean(const float* x, int64_t batch_stride, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

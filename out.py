@@ -1,0 +1,124 @@
+"""Inference + save harness of the stitching path (re-statement of the reference's out.py:15-54,106-146,158-275,
+SURVEY.md section 8 f-1) on the MI355X package.
+
+    python out.py --data_root_path ./demo/ --inf_cfg all_img1_with_inpaint_g12_transRef [--restore_ckpt CKPT]
+
+Same flags, `demo.txt` pair list (one directory per line holding input1.jpg / input2.jpg), RGB-float loading and
+result-directory naming as the reference.  The forward (`type="test_out"`) runs on the HIP kernels; its images are
+written as JPEGs.  The TPS / inpainting post-pipeline (core/inference/**, section 8 f-3) is out of scope this round,
+so `ave_fusion.jpg` holds the forward's own `blend_image` (the reference writes the post-TPS blend there)."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def get_config(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--data_root_path", type=str, default="./demo/")
+    p.add_argument("--txt_file", type=str, default="demo.txt")
+    p.add_argument("--result_dir", type=str, default="results")
+    p.add_argument("--restore_ckpt", type=str, default="")
+    p.add_argument("--model_config_name", type=str, default="last_config")
+    p.add_argument("--inf_cfg", type=str, default="all_img1_with_inpaint_g12_transRef")
+    p.add_argument("--gpu", type=int, default=0)
+    p.add_argument("--skip_if_avg_fusion_exists", action="store_true")
+    args = p.parse_args(argv)
+    import stitch_amd
+    cfg, tps = stitch_amd.load_inference_config(args.inf_cfg, args.model_config_name)
+    for k, v in vars(args).items():
+        if k == "restore_ckpt" and not v:
+            continue
+        cfg[k] = v
+    cfg.TPS_PIPELINE_CONFIG = tps
+    return cfg
+
+
+def get_data_dict_list(data_root_path, txt_file):
+    """out.py:106-123: one pair directory per line of the list file."""
+    out = []
+    with open(os.path.join(data_root_path, txt_file)) as f:
+        for line in f:
+            if line.strip():
+                out.append({"DATA_PATH": os.path.join(data_root_path, line.strip()), "IMG1": "input1.jpg", "IMG2": "input2.jpg"})
+    return out
+
+
+def loadSingleData(data_path, img1_name, img2_name, resize_to_512=False):
+    """out.py:129-146 (cv2.imread + BGR->RGB there; PIL RGB decode here) -> two float [1,3,H,W] tensors, 0..255."""
+    from PIL import Image
+    ts = []
+    for name in (img1_name, img2_name):
+        arr = np.array(Image.open(os.path.join(data_path, name)).convert("RGB")).astype(np.uint8)[..., :3]
+        ts.append(torch.from_numpy(arr.copy()).permute(2, 0, 1).float().unsqueeze(0))
+    if resize_to_512:
+        import stitch_amd
+        ts = [stitch_amd.ops.resize_bilinear(t.cuda(), 512, 512, False).cpu() for t in ts]
+    return ts[0], ts[1]
+
+
+def to_pillow(t):
+    from PIL import Image
+    arr = t[0].detach().cpu().permute(1, 2, 0).clip(0, 255).to(torch.uint8).numpy()
+    return Image.fromarray(arr)
+
+
+@torch.no_grad()
+def inference_one_data(cfg, data_dict, save_root_path, warp_model):
+    """out.py:158-275 up to the saves (without the TPS / inpainting post-pipeline)."""
+    from PIL import Image
+    path = data_dict["DATA_PATH"]
+    name = os.path.basename(os.path.normpath(path))
+    result_path = os.path.join(save_root_path, name) + "/"
+    os.makedirs(result_path, exist_ok=True)
+    image1, image2 = loadSingleData(path if path.endswith("/") else path + "/", data_dict["IMG1"], data_dict["IMG2"],
+                                    resize_to_512=cfg.resize_to_512)
+    if getattr(cfg, "swap_image", False):
+        image1, image2 = image2, image1
+    out = warp_model(image1.cuda(), image2.cuda(), type="test_out", pad_mode=cfg.pad_mode)
+    to_pillow(out["H_warp"]).save(result_path + "H_warp.jpg")
+    to_pillow(out["final_warp"]).save(result_path + "flow_warp.jpg")
+    to_pillow(out["output1"]).save(result_path + "warp1.jpg")
+    to_pillow(out["output2"]).save(result_path + "warp2.jpg")
+    for key in ("mask1", "mask2"):
+        m = (out[key] > 0.5)[0, 0].cpu().to(torch.uint8).numpy() * 255
+        Image.fromarray(m).save(result_path + key + ".jpg")
+    to_pillow(out["blend_image"].float()).save(result_path + "ave_fusion.jpg")
+    return out, result_path
+
+
+def main(argv=None):
+    import stitch_amd
+    cfg = get_config(argv)
+    torch.cuda.set_device(cfg.gpu)
+    model = stitch_amd.build_model(cfg)
+    if cfg.restore_ckpt:
+        model.load_state_dict(torch.load(cfg.restore_ckpt, map_location="cpu", weights_only=True), strict=True)
+    else:
+        print("[out.py] no --restore_ckpt given: running with random-init weights (plumbing only)")
+    model = model.cuda().eval()
+    model_name = cfg.restore_ckpt.split("/")[-2] if cfg.restore_ckpt.count("/") >= 1 else "random"
+    tag = "512" if cfg.resize_to_512 else ""
+    tps = cfg.TPS_PIPELINE_CONFIG
+    suffix = f"{tag}_{model_name}_{tps.get_pt_methods[0]}_{tps.mix_method}_g{tps.grid_h}"
+    save_root = os.path.abspath(os.path.join(cfg.data_root_path, f"../{cfg.result_dir}/")) + f"/ours_{suffix}/"
+    os.makedirs(save_root, exist_ok=True)
+    with open(save_root + "config.txt", "w") as f:
+        f.write(repr(dict(cfg)))
+    for dd in get_data_dict_list(cfg.data_root_path, cfg.txt_file):
+        if cfg.skip_if_avg_fusion_exists and os.path.exists(os.path.join(save_root, os.path.basename(os.path.normpath(dd["DATA_PATH"])), "ave_fusion.jpg")):
+            print("[WARNING] Skip, Due to exist", dd["DATA_PATH"])
+            continue
+        _, rp = inference_one_data(cfg, dd, save_root, model)
+        print("saved", rp)
+    return save_root
+
+
+if __name__ == "__main__":
+    main()

@@ -330,3 +330,19 @@ def tps_transform(U, source, target, out_hw, want_idx=False):
     check(lib.st_tps_solve_grid(_p(U), _p(source.contiguous()), _p(target.contiguous()), _p(work), _p(T), _p(out), _p(idx),
                                 B, Cc, H, W, N, oh, ow, _stream()), "st_tps_solve_grid")
     return (out, T, idx) if want_idx else (out, T)
+
+
+# ---- evaluation metric --------------------------------------------------------------------------
+def masked_psnr_ssim(image1, final_warp_output):
+    """evaluate.py:44-59 on the GPU: image1 [B,3,H,W], final_warp_output [B,6,H,W] -> fp64 [B,2] (psnr, ssim)."""
+    B, _, H, W = image1.shape
+    dev = image1.device
+    valid = torch.empty((B, H, W), device=dev, dtype=torch.float32)
+    mask = final_warp_output[:, 3:6]
+    check(lib.st_channel_mean(_p(mask), final_warp_output.stride(0), _p(valid), B, 3, H, W, _stream()), "st_channel_mean")
+    nblk = (3 * H * W + 255) // 256
+    partial = torch.empty((2 * B * nblk,), device=dev, dtype=torch.float64)
+    out = torch.empty((B, 2), device=dev, dtype=torch.float64)
+    check(lib.st_masked_psnr_ssim(_pc(image1), _p(final_warp_output), final_warp_output.stride(0), _p(valid), _p(partial), _p(out),
+                                  B, H, W, _stream()), "st_masked_psnr_ssim")
+    return out

@@ -79,3 +79,24 @@ def test_prepack_layouts(seeded_sd):
     c1 = pk["dec"]["convc1"][0]
     w = seeded_sd["flow_backbone.memory_decoder.update_block.encoder.convc1.weight"].reshape(256, 145)
     assert torch.equal(c1[:, :81], w[:, 64:]) and torch.equal(c1[:, 84:], w[:, :64]) and (c1[:, 81:84] == 0).all()
+
+
+def test_metric_oracle_and_summary_split():
+    """f-2 host logic: skimage-0.19 restatement sanity + evaluate.py:76-93 slices (the worst pair is dropped)."""
+    import numpy as np
+    from oracle import metrics
+    from stitch_amd import evaluate as ev
+    rs = np.random.RandomState(0)
+    a = rs.randint(0, 256, size=(40, 50, 3)).astype(np.uint8)
+    assert metrics.ssim(a, a) == pytest.approx(1.0, abs=1e-12)
+    b = np.clip(a.astype(np.int32) + rs.randint(-5, 6, size=a.shape), 0, 255).astype(np.uint8)
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    assert metrics.psnr(a, b) == pytest.approx(10 * np.log10(255.0 ** 2 / mse))
+    assert 0.5 < metrics.ssim(a, b) < 1.0
+    img = rs.rand(3, 20, 20).astype(np.float32) * 300 - 20
+    x, y = metrics.masked_uint8_pair(img, img, np.full((1, 20, 20), 0.99, np.float32))
+    assert x.max() == 0 and y.max() == 0                       # mask mean < 1 truncates to 0 (evaluate.py:55)
+    p = list(range(1106, 0, -1))
+    res = ev.summarize(p, p)
+    assert res["easy_psnr"] == pytest.approx(np.mean(p[0:331])) and res["mid_psnr"] == pytest.approx(np.mean(p[331:663]))
+    assert res["hard_psnr"] == pytest.approx(np.mean(p[663:-1])) and res["avg_psnr"] == pytest.approx(np.mean(p))

@@ -117,3 +117,68 @@ def test_rejects_unsupported_requests(model):
         model(x, x, type="bogus")
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 500, 500, device="cuda"), torch.zeros(1, 3, 500, 500, device="cuda"), type="test_eval")
+
+
+def test_masked_psnr_ssim_kernel_vs_metric_oracle(ops):
+    """f-2: evaluate.py:53-59 metric on the GPU vs the numpy/scipy restatement of skimage 0.19 (unpinned vs skimage)."""
+    from oracle import metrics
+    gg = g(80)
+    B, H, W = 3, 96, 128
+    img = (torch.rand(B, 3, H, W, generator=gg) * 255).round()
+    noise = torch.randn(B, 3, H, W, generator=gg) * torch.tensor([2.0, 10.0, 40.0]).view(B, 1, 1, 1)
+    warped = (img + noise).clamp(-20, 280)                                    # exercises the uint8 clip
+    mask3 = torch.ones(B, 3, H, W)
+    mask3[:, :, :, 100:] = 0                                                  # invalid strip
+    mask3[1, 0, 10:20, 10:20] = 0.5                                           # mean < 1 -> uint8 truncation to 0
+    fwo = torch.cat([warped * (mask3.mean(1, keepdim=True) > 0), mask3], 1)
+    got = ops.masked_psnr_ssim(img.cuda(), fwo.cuda().contiguous()).cpu().numpy()
+    for b in range(B):
+        p, s = metrics.pair_metrics(img[b].numpy(), fwo[b, :3].numpy(), fwo[b, 3:6].mean(0, keepdim=True).numpy())
+        assert abs(got[b, 0] - p) < 1e-9 * max(1.0, abs(p)), (got[b, 0], p)       # integer-exact MSE
+        assert abs(got[b, 1] - s) < 1e-9, (got[b, 1], s)
+    again = ops.masked_psnr_ssim(img.cuda(), fwo.cuda().contiguous()).cpu().numpy()
+    assert np.array_equal(got, again)                                             # deterministic reduction
+
+
+def test_validate_with_model_harness(model, tmp_path):
+    """f-2 harness: UDISDataset (PIL) -> sharded validate -> reference summary keys."""
+    from PIL import Image
+    import stitch_amd
+    from stitch_amd import evaluate as ev
+    for i in range(3):
+        a, b = inputs.structured_pair(512, 512, seed=50 + i)
+        for name, t in (("input1", a), ("input2", b)):
+            d = tmp_path / "testing" / name
+            d.mkdir(parents=True, exist_ok=True)
+            Image.fromarray(t[0].permute(1, 2, 0).byte().numpy()).save(str(d / f"{i:06d}.jpg"), quality=95)
+    ds = ev.UDISDataset(str(tmp_path) + "/")
+    assert len(ds) == 3 and ds[0][0].shape == (3, 512, 512)
+    res, table = ev.validate_with_model(model, ds, batch_size=2)
+    assert set(res) == {"avg_psnr", "avg_ssim", "easy_psnr", "mid_psnr", "hard_psnr", "easy_ssim", "mid_ssim", "hard_ssim"}
+    assert table.shape == (3, 2) and torch.isfinite(table).all() and 0 < res["avg_ssim"] <= 1.0
+
+
+def test_out_harness_writes_the_reference_file_set(tmp_path, seeded_sd):
+    """f-1: out.py flags / demo.txt list / result naming / the 7 JPEGs, on the 256x256 demo1 pair held as fixture data."""
+    import os
+    from PIL import Image
+    sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("stitch_out_harness", os.path.join(sys_path_root, "out.py"))
+    outmod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(outmod)
+    g_ = np.load(os.path.join(sys_path_root, "tests", "golden", "e2e_out_256.npz"))
+    root = tmp_path / "demo"
+    (root / "demo1").mkdir(parents=True)
+    Image.fromarray(g_["input1"]).save(str(root / "demo1" / "input1.jpg"), quality=98)
+    Image.fromarray(g_["input2"]).save(str(root / "demo1" / "input2.jpg"), quality=98)
+    (root / "demo.txt").write_text("demo1/\n")
+    ck = tmp_path / "ckpts" / "seeded" / "final_ckpt"
+    ck.parent.mkdir(parents=True)
+    torch.save({"module." + k: v for k, v in seeded_sd.items()}, str(ck))
+    save_root = outmod.main(["--data_root_path", str(root) + "/", "--restore_ckpt", str(ck)])
+    assert "ours__seeded_advanced_uniform_multi_all_img1_with_inpaint_g12" in save_root
+    files = sorted(os.listdir(os.path.join(save_root, "demo1")))
+    assert files == sorted(["H_warp.jpg", "flow_warp.jpg", "warp1.jpg", "warp2.jpg", "mask1.jpg", "mask2.jpg", "ave_fusion.jpg"])
+    im = Image.open(os.path.join(save_root, "demo1", "ave_fusion.jpg"))
+    assert abs(im.size[0] - 256) < 64 and abs(im.size[1] - 256) < 64
