@@ -72,6 +72,101 @@ __device__ __forceinline__ void gemm_store(const st_gemm_desc& d, float* __restr
     C[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, acc, sc);
 }
 
+// Epilogue shared by the fp32 and the split-bf16 kernels.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_tile_epilogue(const st_gemm_desc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                                   int wm, int wn, int li, int lh, int split, int kz) {
+    // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li] of the 32x32 tile.  All mode switches are
+    // wave-uniform and sit OUTSIDE the 16-register loops, and the operand loads of a 16-row column are issued
+    // back to back from clamped rows (a per-element switch serialised 16 dependent L2 round trips: ~9 us per launch).
+    const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
+    const int half = d.N >> 1;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * TN * 32 + jn * 32 + li;
+        const bool ncol = n < d.N;
+        const int nc = ncol ? n : d.N - 1;
+        const float bv = d.bias ? d.bias[nc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * lh;
+            int mr[16];
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                ok[r] = ncol && m < d.M;
+                mr[r] = m < d.M ? m : d.M - 1;
+            }
+            if (split > 1) {                                   // raw partial sums -> slab
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok[r]) d.workspace[((size_t)kz * d.M + mr[r]) * d.N + n] = acc[i][jn][r];
+                continue;
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][jn][r] * d.alpha + bv;
+            if (d.aux0) {
+                float a0[16];
+                if (d.aux0_row_div > 1 || d.aux0_row_mod > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int ar = mr[r];
+                        if (d.aux0_row_div > 1) ar = ar / d.aux0_row_div;
+                        if (d.aux0_row_mod > 0) ar = ar % d.aux0_row_mod;
+                        a0[r] = d.aux0[(size_t)ar * d.ld_aux0 + nc];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a0[r] = d.aux0[(size_t)mr[r] * d.ld_aux0 + nc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += a0[r];
+            }
+            if (d.act != ST_ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = st_act(v[r], d.act);
+            }
+            if (d.epi == ST_EPI_STORE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = v[r];
+            } else if (d.epi == ST_EPI_ZR) {
+                if (nc < half) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = v[r];
+                } else {
+                    float h[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h[r] = d.aux1[(size_t)mr[r] * d.ld_aux1 + (nc - half)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (ok[r]) d.c2[(size_t)mr[r] * d.ldc2 + (n - half)] = v[r] * h[r];
+                }
+            } else {
+                float x1[16], x2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x1[r] = d.aux1[(size_t)mr[r] * d.ld_aux1 + nc];
+                if (d.epi == ST_EPI_GRU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x2[r] = d.aux2[(size_t)mr[r] * d.ld_aux2 + nc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float o = v[r];
+                    if (d.epi == ST_EPI_ADD) o = v[r] + x1[r];
+                    else if (d.epi == ST_EPI_MUL) o = v[r] * x1[r];
+                    else if (d.epi == ST_EPI_GRU) o = (1.0f - x1[r]) * x2[r] + x1[r] * v[r];
+                    else if (d.epi == ST_EPI_AXPY) o = x1[r] + sc * v[r];
+                    if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = o;
+                }
+            }
+        }
+    }
+}
+
 template <int WARPS_M, int WARPS_N, int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
     constexpr int BM = WARPS_M * TM * 32;
@@ -244,95 +339,175 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
         __syncthreads();
     }
 
-    // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li] of the 32x32 tile.  All mode switches are
-    // wave-uniform and sit OUTSIDE the 16-register loops, and the operand loads of a 16-row column are issued
-    // back to back from clamped rows (a per-element switch serialised 16 dependent L2 round trips: ~9 us per launch).
-    const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
-    const int half = d.N >> 1;
+    gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand is split EXACTLY into three bf16 parts
+// (x = x1 + x2 + x3, 8 mantissa bits each) while it is staged into LDS, and the product keeps the six partial
+// products of order <= 2^-16 (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2) accumulated in fp32.  The dropped terms are
+// <= 2^-23 relative -- below fp32's own rounding -- so the result is fp32-grade (measured: error vs fp64 at or
+// below the fp32 fmaf chain's), but 16 k cost 6 x 32 cycles of v_mfma_f32_32x32x16_bf16 instead of 8 x 64
+// cycles of v_mfma_f32_32x32x2_f32 (2.7x less matrix-pipe time).  64x64 tile, 4 waves, BK = 32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define SP_LD 40                  // bf16 per LDS row (32 + 8 pad): 80-B rows, conflict-free 16-B fragment reads
+#define SP_PLANE (64 * SP_LD)     // one 64-row plane, in bf16 elements
+
+__device__ __forceinline__ void split3_store(unsigned short* __restrict__ base, float4 v) {
+    // base -> plane 0 of this (row, kcol); planes are SP_PLANE apart
+    float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned short h1[4], h2[4], h3[4];
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int n = n0 + wn * TN * 32 + jn * 32 + li;
-        const bool ncol = n < d.N;
-        const int nc = ncol ? n : d.N - 1;
-        const float bv = d.bias ? d.bias[nc] : 0.f;
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 b1 = (__bf16)x[e];
+        const float r1 = x[e] - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const float r2 = r1 - (float)b2;
+        const __bf16 b3 = (__bf16)r2;
+        h1[e] = __builtin_bit_cast(unsigned short, b1);
+        h2[e] = __builtin_bit_cast(unsigned short, b2);
+        h3[e] = __builtin_bit_cast(unsigned short, b3);
+    }
+    *reinterpret_cast<uint2*>(base) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
+    *reinterpret_cast<uint2*>(base + SP_PLANE) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
+    *reinterpret_cast<uint2*>(base + 2 * SP_PLANE) = make_uint2(h3[0] | ((unsigned)h3[1] << 16), h3[2] | ((unsigned)h3[3] << 16));
+}
+
+// PRESPLIT: W arrives already split (three bf16 planes [N, ldw], w_plane_stride elements apart, prepared once
+// per checkpoint load) so only the activation operand pays the split arithmetic.
+template <bool PRESPLIT>
+__global__ __launch_bounds__(256) void conv_gemm_bf16x6_kernel(const st_gemm_desc d) {
+    constexpr int BM = 64, BN = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    // [2 buffers][A: 3 planes | B: 3 planes][64 rows][SP_LD]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int split = d.split_k > 1 ? d.split_k : 1;
+    const int bz = split > 1 ? 0 : blockIdx.z;
+    const int kz = split > 1 ? blockIdx.z : 0;
+    const float* __restrict__ X = d.a + (size_t)bz * d.batch_stride_a;
+    const float* __restrict__ Wt = d.w + (size_t)bz * d.batch_stride_w;
+    float* __restrict__ C = d.c + (size_t)bz * d.batch_stride_c;
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % ntn, tile_m = bid / ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int K = d.K;
+    const int kcol = (tid & 7) * 4;
+    const int rrow = tid >> 3;
+    int a_ok[2], a_iy0[2], a_ix0[2], a_b[2];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * lh;
-            int mr[16];
-            bool ok[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                ok[r] = ncol && m < d.M;
-                mr[r] = m < d.M ? m : d.M - 1;
+    for (int p = 0; p < 2; ++p) {
+        const int m = m0 + rrow + 32 * p;
+        a_ok[p] = m < d.M;
+        const int mm = a_ok[p] ? m : 0;
+        const int hw = d.Ho * d.Wo;
+        const int b = mm / hw, r = mm - b * hw;
+        const int oy = r / d.Wo, ox = r - oy * d.Wo;
+        a_b[p] = b; a_iy0[p] = oy * d.sh - d.ph; a_ix0[p] = ox * d.sw - d.pw;
+    }
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)d.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, (int)d.w_bytes, 0x00020000);
+    float4 ra[2], rb[2];
+    uint2 rbs[2][3];
+    int t_ky = 0, t_kx = 0, t_c = 0, t_kt = -2;
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kcol;
+        if (d.kh * d.kw > 1) {
+            if (t_kt + 1 == kt && d.Cin >= BK) {
+                t_c += BK;
+                if (t_c >= d.Cin) { t_c -= d.Cin; if (++t_kx == d.kw) { t_kx = 0; ++t_ky; } }
+            } else {
+                const int kyx = k / d.Cin;
+                t_c = k - kyx * d.Cin; t_ky = kyx / d.kw; t_kx = kyx - t_ky * d.kw;
             }
-            if (split > 1) {                                   // raw partial sums -> slab
+            t_kt = kt;
+        } else { t_c = k; }
+        const bool kin = k < K;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (ok[r]) d.workspace[((size_t)kz * d.M + mr[r]) * d.N + n] = acc[i][jn][r];
-                continue;
-            }
-            float v[16];
+        for (int p = 0; p < 2; ++p) {
+            const int iy = a_iy0[p] + t_ky, ix = a_ix0[p] + t_kx;
+            const bool ok = kin && a_ok[p] && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+            const unsigned off = ok ? (unsigned)(((a_b[p] * d.H + iy) * d.W + ix) * d.ldx + t_c) * 4u : ST_OOB;
+            ra[p] = buf_load16(rsrcA, off);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[i][jn][r] * d.alpha + bv;
-            if (d.aux0) {
-                float a0[16];
-                if (d.aux0_row_div > 1 || d.aux0_row_mod > 0) {
+        for (int p = 0; p < 2; ++p) {
+            const int n = n0 + rrow + 32 * p;
+            const bool ok = kin && n < d.N;
+            if constexpr (PRESPLIT) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int ar = mr[r];
-                        if (d.aux0_row_div > 1) ar = ar / d.aux0_row_div;
-                        if (d.aux0_row_mod > 0) ar = ar % d.aux0_row_mod;
-                        a0[r] = d.aux0[(size_t)ar * d.ld_aux0 + nc];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a0[r] = d.aux0[(size_t)mr[r] * d.ld_aux0 + nc];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += a0[r];
-            }
-            if (d.act != ST_ACT_NONE) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = st_act(v[r], d.act);
-            }
-            if (d.epi == ST_EPI_STORE) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = v[r];
-            } else if (d.epi == ST_EPI_ZR) {
-                if (nc < half) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = v[r];
-                } else {
-                    float h[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) h[r] = d.aux1[(size_t)mr[r] * d.ld_aux1 + (nc - half)];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (ok[r]) d.c2[(size_t)mr[r] * d.ldc2 + (n - half)] = v[r] * h[r];
+                for (int q = 0; q < 3; ++q) {
+                    const unsigned off = ok ? (unsigned)(q * (int)d.w_plane_stride + n * d.ldw + k) * 2u : ST_OOB;
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrcW, (int)off, 0, 0);
+                    rbs[p][q] = make_uint2(v.x, v.y);
                 }
             } else {
-                float x1[16], x2[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x1[r] = d.aux1[(size_t)mr[r] * d.ld_aux1 + nc];
-                if (d.epi == ST_EPI_GRU) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) x2[r] = d.aux2[(size_t)mr[r] * d.ld_aux2 + nc];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float o = v[r];
-                    if (d.epi == ST_EPI_ADD) o = v[r] + x1[r];
-                    else if (d.epi == ST_EPI_MUL) o = v[r] * x1[r];
-                    else if (d.epi == ST_EPI_GRU) o = (1.0f - x1[r]) * x2[r] + x1[r] * v[r];
-                    else if (d.epi == ST_EPI_AXPY) o = x1[r] + sc * v[r];
-                    if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = o;
-                }
+                const unsigned off = ok ? (unsigned)(n * d.ldw + k) * 4u : ST_OOB;
+                rb[p] = buf_load16(rsrcW, off);
             }
         }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned short* Ab = smem16 + (size_t)buf * 6 * SP_PLANE;
+        unsigned short* Bb = Ab + 3 * SP_PLANE;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            split3_store(Ab + (rrow + 32 * p) * SP_LD + kcol, ra[p]);
+            if constexpr (PRESPLIT) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    *reinterpret_cast<uint2*>(Bb + q * SP_PLANE + (rrow + 32 * p) * SP_LD + kcol) = rbs[p][q];
+            } else {
+                split3_store(Bb + (rrow + 32 * p) * SP_LD + kcol, rb[p]);
+            }
+        }
+    };
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    const int nkt_all = (K + BK - 1) / BK;
+    const int per = (nkt_all + split - 1) / split;
+    const int kt0 = kz * per;
+    const int nkt = min(nkt_all, kt0 + per);
+    const int li = lane & 31, lh = lane >> 5;
+    if (kt0 < nkt) {
+        load_tile(kt0);
+        store_tile(kt0 & 1);
     }
+    __syncthreads();
+    for (int kt = kt0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const unsigned short* Ab = smem16 + (size_t)buf * 6 * SP_PLANE + (wm * 32 + li) * SP_LD + 8 * lh;
+        const unsigned short* Bb = smem16 + (size_t)buf * 6 * SP_PLANE + 3 * SP_PLANE + (wn * 32 + li) * SP_LD + 8 * lh;
+#pragma unroll
+        for (int c = 0; c < BK / 16; ++c) {
+            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + 16 * c);
+            bf16x8 a2 = *reinterpret_cast<const bf16x8*>(Ab + SP_PLANE + 16 * c);
+            bf16x8 a3 = *reinterpret_cast<const bf16x8*>(Ab + 2 * SP_PLANE + 16 * c);
+            bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bb + 16 * c);
+            bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bb + SP_PLANE + 16 * c);
+            bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bb + 2 * SP_PLANE + 16 * c);
+            // smallest partial products first
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[0][0], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    gemm_tile_epilogue<1, 1>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
 }
 
 // split-K tail: sum the K-slice slabs [split][M][N] in slice order (deterministic) + epilogue.
@@ -396,6 +571,8 @@ static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
     return ST_OK;
 }
 
+static inline bool batch_is_many(const st_gemm_desc& d) { return d.batch > 1; }
+
 extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
     if (!desc) return ST_EINVAL;
     st_gemm_desc d = *desc;
@@ -409,11 +586,15 @@ extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
     // out-of-range sentinel offset is always past num_records)
     {
         const int64_t a_rows = (int64_t)(d.M / (d.Ho * d.Wo)) * d.H * d.W;
-        const int64_t ab = ((a_rows - 1) * d.ldx + d.Cin) * 4, wb = ((int64_t)(d.N - 1) * d.ldw + d.K) * 4;
+        const int64_t ab = ((a_rows - 1) * d.ldx + d.Cin) * 4;
+        const int64_t wb = d.w_presplit ? (2 * d.w_plane_stride + (int64_t)(d.N - 1) * d.ldw + d.K) * 2
+                                        : ((int64_t)(d.N - 1) * d.ldw + d.K) * 4;
         if (ab >= (int64_t)ST_OOB || wb >= (int64_t)ST_OOB) return ST_EINVAL;
         d.a_bytes = (uint32_t)ab; d.w_bytes = (uint32_t)wb;
     }
-    const bool aligned = ((uintptr_t)d.a % 16 == 0) && ((uintptr_t)d.w % 16 == 0) && (d.ldx % 4 == 0) &&
+    if (d.w_presplit && (d.precision != 1 || batch_is_many(d) || ((uintptr_t)d.w % 8) || (d.ldw % 4) || (d.w_plane_stride % 4)))
+        return ST_EINVAL;
+    const bool aligned = ((uintptr_t)d.a % 16 == 0) && ((uintptr_t)d.w % (d.w_presplit ? 8 : 16) == 0) && (d.ldx % 4 == 0) &&
                          (d.ldw % 4 == 0) && (d.Cin % 4 == 0) &&
                          (d.batch_stride_a % 4 == 0) && (d.batch_stride_w % 4 == 0);
     const int batch = d.batch > 0 ? d.batch : 1;
@@ -448,6 +629,25 @@ extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
     }
     if (split > 1 && (batch != 1 || !d.workspace || (int64_t)split * d.M * d.N > d.workspace_floats)) return ST_EINVAL;
     d.split_k = split;
+    if (d.w_presplit && !(aligned && cfg == 3)) return ST_EINVAL;   // pre-split weights only feed the split kernel
+    if (d.precision == 1 && aligned && cfg == 3) {      // fp32-grade split-bf16 kernel (64x64 tile, 16-B aligned operands)
+        const int ntm = (d.M + 63) / 64, ntn = (d.N + 63) / 64;
+        dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : batch);
+        const size_t lds = (size_t)2 * 6 * SP_PLANE * sizeof(unsigned short);
+        if (d.w_presplit) {
+            auto kern = conv_gemm_bf16x6_kernel<true>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+        } else {
+            auto kern = conv_gemm_bf16x6_kernel<false>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+        }
+        if (d.split_k > 1)
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(((size_t)d.M * d.N + 255) / 256), dim3(256), 0, s, d);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     switch (cfg) {
         case 1: return launch_cfg<2, 2, 2, 2>(d, aligned, s);
         case 2: return launch_cfg<2, 2, 2, 1>(d, aligned, s);

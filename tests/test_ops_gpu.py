@@ -142,6 +142,35 @@ def test_patch_conv1_direct(ops):
     assert (from_rows(out, 5, 8, 8) - ref).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("presplit", [False, True])
+def test_gemm_bf16x6_split_precision_is_fp32_grade(ops, presplit):
+    """precision=1: exact 3-way bf16 split, six partial products on the bf16 MFMA, fp32 accumulate -- error vs
+    fp64 must stay at the level of the exact-fp32 kernel (it is an opt-in, the default path is precision=0)."""
+    M, N, K = 3000, 200, 1920
+    a, w = torch.randn(M, K, generator=g(90)), torch.randn(N, K, generator=g(91)) / K ** 0.5
+    bias = torch.randn(N, generator=g(92))
+    ref = F.linear(a.double(), w.double(), bias.double())
+    ad, wd = dev(a), dev(w)
+    if presplit:
+        ops.SPLIT_WEIGHTS.register("test", [wd])
+    o0, o1 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.conv_gemm(ad, wd, o0, bias=dev(bias), precision=0)
+    ops.conv_gemm(ad, wd, o1, bias=dev(bias), precision=1)
+    e0, e1 = (o0.cpu().double() - ref).abs().max().item(), (o1.cpu().double() - ref).abs().max().item()
+    assert e1 < 2e-5 and e1 < 2.0 * e0 + 1e-6, (e0, e1)
+    if presplit:      # a row/column slice of a registered weight resolves to the same planes
+        ops.conv_gemm(ad[:, 64:], wd[8:136, 64:], o1[:, :128], precision=1)
+        r2 = a[:, 64:].double() @ w[8:136, 64:].double().t()
+        assert (o1[:, :128].cpu().double() - r2).abs().max() < 2e-5
+        ops.SPLIT_WEIGHTS.drop("test")
+    x = torch.randn(2, 64, 12, 16, generator=g(93))
+    cw = torch.randn(96, 64, 3, 3, generator=g(94)) / 24
+    refc = F.conv2d(x, cw, padding=1)
+    out = torch.empty(2 * 12 * 16, 96, device="cuda")
+    ops.conv_gemm(nhwc(x), pack_conv_w(cw), out, geom=(2, 12, 16, 3, 3, 1, 1, 1, 1), precision=1, split_k=3)
+    assert (from_rows(out, 2, 12, 16) - refc).abs().max() < 2e-5
+
+
 def test_corr_volume(ops):
     f1, f2 = torch.randn(2, 256, 16, 16, generator=g(13)), torch.randn(2, 256, 16, 16, generator=g(14))
     ref = nets.corr_volume(f1, f2)
