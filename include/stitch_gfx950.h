@@ -50,9 +50,6 @@ typedef struct st_gemm_desc {
     uint32_t a_bytes, w_bytes;  /* filled by the library: extents of A / W for the buffer descriptors  */
     int32_t precision;     /* 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain); 1: fp32-grade bf16x6 split
                               (x = x1+x2+x3 exactly in bf16, six partial products, fp32 accumulate)       */
-    int32_t w_presplit;    /* 1: w points at three bf16 planes [N, ldw] (exact 3-way split of the fp32
-                              weights, prepared once), w_plane_stride elements apart; needs precision 1   */
-    int64_t w_plane_stride;
 } st_gemm_desc;
 
 /* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.

@@ -343,43 +343,37 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp32 GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand is split EXACTLY into three bf16 parts
-// (x = x1 + x2 + x3, 8 mantissa bits each) while it is staged into LDS, and the product keeps the six partial
-// products of order <= 2^-16 (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2) accumulated in fp32.  The dropped terms are
-// <= 2^-23 relative -- below fp32's own rounding -- so the result is fp32-grade (measured: error vs fp64 at or
-// below the fp32 fmaf chain's), but 16 k cost 6 x 32 cycles of v_mfma_f32_32x32x16_bf16 instead of 8 x 64
-// cycles of v_mfma_f32_32x32x2_f32 (2.7x less matrix-pipe time).  64x64 tile, 4 waves, BK = 32.
+// fp32 GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand value is split EXACTLY into three bf16 parts
+// (x = x1 + x2 + x3, 8 significant bits each) and the product keeps the six partial products of order <= 2^-16
+// (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2) accumulated in fp32.  The dropped terms are <= 2^-23 relative -- below fp32's
+// own rounding -- so the result is fp32-grade (measured: error vs fp64 at or below the fmaf-chain kernel's), but
+// 16 k cost 6 x 32 cycles of v_mfma_f32_32x32x16_bf16 instead of 8 x 64 cycles of v_mfma_f32_32x32x2_f32.
+// Same staging as the fp32 kernel (fp32 tiles in LDS, so LDS traffic does not grow); the split runs in registers
+// on each wave's fragments, on the VALU, concurrently with other waves' MFMAs.  (A first version that split at
+// LDS-store time into three bf16 planes was LDS-bound: 12 ds_write_b64 + 12 ds_read_b128 per thread and K step.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define SP_LD 40                  // bf16 per LDS row (32 + 8 pad): 80-B rows, conflict-free 16-B fragment reads
-#define SP_PLANE (64 * SP_LD)     // one 64-row plane, in bf16 elements
 
-__device__ __forceinline__ void split3_store(unsigned short* __restrict__ base, float4 v) {
-    // base -> plane 0 of this (row, kcol); planes are SP_PLANE apart
-    float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned short h1[4], h2[4], h3[4];
+__device__ __forceinline__ void split8(const float4 lo, const float4 hi, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 8; ++e) {
         const __bf16 b1 = (__bf16)x[e];
         const float r1 = x[e] - (float)b1;
         const __bf16 b2 = (__bf16)r1;
         const float r2 = r1 - (float)b2;
-        const __bf16 b3 = (__bf16)r2;
-        h1[e] = __builtin_bit_cast(unsigned short, b1);
-        h2[e] = __builtin_bit_cast(unsigned short, b2);
-        h3[e] = __builtin_bit_cast(unsigned short, b3);
+        p1[e] = b1; p2[e] = b2; p3[e] = (__bf16)r2;
     }
-    *reinterpret_cast<uint2*>(base) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
-    *reinterpret_cast<uint2*>(base + SP_PLANE) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
-    *reinterpret_cast<uint2*>(base + 2 * SP_PLANE) = make_uint2(h3[0] | ((unsigned)h3[1] << 16), h3[2] | ((unsigned)h3[3] << 16));
 }
 
-// PRESPLIT: W arrives already split (three bf16 planes [N, ldw], w_plane_stride elements apart, prepared once
-// per checkpoint load) so only the activation operand pays the split arithmetic.
-template <bool PRESPLIT>
+template <int TM, int TN, int BKT>
 __global__ __launch_bounds__(256) void conv_gemm_bf16x6_kernel(const st_gemm_desc d) {
-    constexpr int BM = 64, BN = 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-    // [2 buffers][A: 3 planes | B: 3 planes][64 rows][SP_LD]
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+    constexpr int LDT = BKT + 4;              // LDS row stride (floats)
+    constexpr int TPR = BKT / 4;              // threads per tile row (one float4 each)
+    constexpr int RPP = 256 / TPR;            // rows staged per pass
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDT;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -399,12 +393,13 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x6_kernel(const st_gemm_des
     const int tile_n = bid % ntn, tile_m = bid / ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int K = d.K;
-    const int kcol = (tid & 7) * 4;
-    const int rrow = tid >> 3;
-    int a_ok[2], a_iy0[2], a_ix0[2], a_b[2];
+    const int kcol = (tid % TPR) * 4;
+    const int rrow = tid / TPR;
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    int a_ok[AP], a_iy0[AP], a_ix0[AP], a_b[AP];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int m = m0 + rrow + 32 * p;
+    for (int p = 0; p < AP; ++p) {
+        const int m = m0 + rrow + RPP * p;
         a_ok[p] = m < d.M;
         const int mm = a_ok[p] ? m : 0;
         const int hw = d.Ho * d.Wo;
@@ -414,14 +409,13 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x6_kernel(const st_gemm_des
     }
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)d.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, (int)d.w_bytes, 0x00020000);
-    float4 ra[2], rb[2];
-    uint2 rbs[2][3];
+    float4 ra[AP], rb[BP];
     int t_ky = 0, t_kx = 0, t_c = 0, t_kt = -2;
     auto load_tile = [&](int kt) {
-        const int k = kt * BK + kcol;
+        const int k = kt * BKT + kcol;
         if (d.kh * d.kw > 1) {
-            if (t_kt + 1 == kt && d.Cin >= BK) {
-                t_c += BK;
+            if (t_kt + 1 == kt && d.Cin >= BKT) {
+                t_c += BKT;
                 if (t_c >= d.Cin) { t_c -= d.Cin; if (++t_kx == d.kw) { t_kx = 0; ++t_ky; } }
             } else {
                 const int kyx = k / d.Cin;
@@ -431,49 +425,36 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x6_kernel(const st_gemm_des
         } else { t_c = k; }
         const bool kin = k < K;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < AP; ++p) {
             const int iy = a_iy0[p] + t_ky, ix = a_ix0[p] + t_kx;
             const bool ok = kin && a_ok[p] && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
             const unsigned off = ok ? (unsigned)(((a_b[p] * d.H + iy) * d.W + ix) * d.ldx + t_c) * 4u : ST_OOB;
             ra[p] = buf_load16(rsrcA, off);
         }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int n = n0 + rrow + 32 * p;
+        for (int p = 0; p < BP; ++p) {
+            const int n = n0 + rrow + RPP * p;
             const bool ok = kin && n < d.N;
-            if constexpr (PRESPLIT) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const unsigned off = ok ? (unsigned)(q * (int)d.w_plane_stride + n * d.ldw + k) * 2u : ST_OOB;
-                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrcW, (int)off, 0, 0);
-                    rbs[p][q] = make_uint2(v.x, v.y);
-                }
-            } else {
-                const unsigned off = ok ? (unsigned)(n * d.ldw + k) * 4u : ST_OOB;
-                rb[p] = buf_load16(rsrcW, off);
-            }
+            const unsigned off = ok ? (unsigned)(n * d.ldw + k) * 4u : ST_OOB;
+            rb[p] = buf_load16(rsrcW, off);
         }
     };
     auto store_tile = [&](int buf) {
-        unsigned short* Ab = smem16 + (size_t)buf * 6 * SP_PLANE;
-        unsigned short* Bb = Ab + 3 * SP_PLANE;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            split3_store(Ab + (rrow + 32 * p) * SP_LD + kcol, ra[p]);
-            if constexpr (PRESPLIT) {
+        for (int p = 0; p < AP; ++p)
+            *reinterpret_cast<float4*>(As + ((size_t)buf * BM + rrow + RPP * p) * LDT + kcol) = ra[p];
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    *reinterpret_cast<uint2*>(Bb + q * SP_PLANE + (rrow + 32 * p) * SP_LD + kcol) = rbs[p][q];
-            } else {
-                split3_store(Bb + (rrow + 32 * p) * SP_LD + kcol, rb[p]);
-            }
-        }
+        for (int p = 0; p < BP; ++p)
+            *reinterpret_cast<float4*>(Bs + ((size_t)buf * BN + rrow + RPP * p) * LDT + kcol) = rb[p];
     };
-    f32x16 acc[1][1];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    const int nkt_all = (K + BK - 1) / BK;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nkt_all = (K + BKT - 1) / BKT;
     const int per = (nkt_all + split - 1) / split;
     const int kt0 = kz * per;
     const int nkt = min(nkt_all, kt0 + per);
@@ -486,28 +467,35 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x6_kernel(const st_gemm_des
     for (int kt = kt0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) load_tile(kt + 1);
-        const unsigned short* Ab = smem16 + (size_t)buf * 6 * SP_PLANE + (wm * 32 + li) * SP_LD + 8 * lh;
-        const unsigned short* Bb = smem16 + (size_t)buf * 6 * SP_PLANE + 3 * SP_PLANE + (wn * 32 + li) * SP_LD + 8 * lh;
+        const float* Ab = As + ((size_t)buf * BM + wm * TM * 32 + li) * LDT + 8 * lh;
+        const float* Bb = Bs + ((size_t)buf * BN + wn * TN * 32 + li) * LDT + 8 * lh;
 #pragma unroll
-        for (int c = 0; c < BK / 16; ++c) {
-            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + 16 * c);
-            bf16x8 a2 = *reinterpret_cast<const bf16x8*>(Ab + SP_PLANE + 16 * c);
-            bf16x8 a3 = *reinterpret_cast<const bf16x8*>(Ab + 2 * SP_PLANE + 16 * c);
-            bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bb + 16 * c);
-            bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bb + SP_PLANE + 16 * c);
-            bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bb + 2 * SP_PLANE + 16 * c);
-            // smallest partial products first
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[0][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[0][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[0][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[0][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[0][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[0][0], 0, 0, 0);
+        for (int c = 0; c < BKT / 16; ++c) {
+            bf16x8 a1[TM], a2[TM], a3[TM], b1[TN], b2[TN], b3[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                split8(*reinterpret_cast<const float4*>(Ab + i * 32 * LDT + 16 * c),
+                       *reinterpret_cast<const float4*>(Ab + i * 32 * LDT + 16 * c + 4), a1[i], a2[i], a3[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                split8(*reinterpret_cast<const float4*>(Bb + j * 32 * LDT + 16 * c),
+                       *reinterpret_cast<const float4*>(Bb + j * 32 * LDT + 16 * c + 4), b1[j], b2[j], b3[j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {       // smallest partial products first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b2[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i], b1[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b3[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b1[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b2[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                }
         }
         if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
     }
-    gemm_tile_epilogue<1, 1>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
+    gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
 }
 
 // split-K tail: sum the K-slice slabs [split][M][N] in slice order (deterministic) + epilogue.
@@ -571,8 +559,6 @@ static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
     return ST_OK;
 }
 
-static inline bool batch_is_many(const st_gemm_desc& d) { return d.batch > 1; }
-
 extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
     if (!desc) return ST_EINVAL;
     st_gemm_desc d = *desc;
@@ -586,15 +572,11 @@ extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
     // out-of-range sentinel offset is always past num_records)
     {
         const int64_t a_rows = (int64_t)(d.M / (d.Ho * d.Wo)) * d.H * d.W;
-        const int64_t ab = ((a_rows - 1) * d.ldx + d.Cin) * 4;
-        const int64_t wb = d.w_presplit ? (2 * d.w_plane_stride + (int64_t)(d.N - 1) * d.ldw + d.K) * 2
-                                        : ((int64_t)(d.N - 1) * d.ldw + d.K) * 4;
+        const int64_t ab = ((a_rows - 1) * d.ldx + d.Cin) * 4, wb = ((int64_t)(d.N - 1) * d.ldw + d.K) * 4;
         if (ab >= (int64_t)ST_OOB || wb >= (int64_t)ST_OOB) return ST_EINVAL;
         d.a_bytes = (uint32_t)ab; d.w_bytes = (uint32_t)wb;
     }
-    if (d.w_presplit && (d.precision != 1 || batch_is_many(d) || ((uintptr_t)d.w % 8) || (d.ldw % 4) || (d.w_plane_stride % 4)))
-        return ST_EINVAL;
-    const bool aligned = ((uintptr_t)d.a % 16 == 0) && ((uintptr_t)d.w % (d.w_presplit ? 8 : 16) == 0) && (d.ldx % 4 == 0) &&
+    const bool aligned = ((uintptr_t)d.a % 16 == 0) && ((uintptr_t)d.w % 16 == 0) && (d.ldx % 4 == 0) &&
                          (d.ldw % 4 == 0) && (d.Cin % 4 == 0) &&
                          (d.batch_stride_a % 4 == 0) && (d.batch_stride_w % 4 == 0);
     const int batch = d.batch > 0 ? d.batch : 1;
@@ -629,20 +611,19 @@ extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
     }
     if (split > 1 && (batch != 1 || !d.workspace || (int64_t)split * d.M * d.N > d.workspace_floats)) return ST_EINVAL;
     d.split_k = split;
-    if (d.w_presplit && !(aligned && cfg == 3)) return ST_EINVAL;   // pre-split weights only feed the split kernel
-    if (d.precision == 1 && aligned && cfg == 3) {      // fp32-grade split-bf16 kernel (64x64 tile, 16-B aligned operands)
-        const int ntm = (d.M + 63) / 64, ntn = (d.N + 63) / 64;
-        dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : batch);
-        const size_t lds = (size_t)2 * 6 * SP_PLANE * sizeof(unsigned short);
-        if (d.w_presplit) {
-            auto kern = conv_gemm_bf16x6_kernel<true>;
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (d.precision == 1 && aligned && (cfg == 3 || cfg == 2 || cfg == 1)) {     // fp32-grade split-bf16 kernel
+        auto launch = [&](auto kern, int bm, int bn) {
+            const int ntm = (d.M + bm - 1) / bm, ntn = (d.N + bn - 1) / bn;
+            dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : batch);
+            const int bkt = d.K >= 256 ? 64 : 32;
+            const size_t lds = (size_t)2 * (bm + bn) * (bkt + 4) * sizeof(float);
+            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
-        } else {
-            auto kern = conv_gemm_bf16x6_kernel<false>;
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
-        }
+        };
+        const bool deep = d.K >= 256;        // 64-deep K steps halve the barriers per FLOP once K is long enough
+        if (cfg == 3) { if (deep) launch(conv_gemm_bf16x6_kernel<1, 1, 64>, 64, 64); else launch(conv_gemm_bf16x6_kernel<1, 1, 32>, 64, 64); }
+        else if (cfg == 2) { if (deep) launch(conv_gemm_bf16x6_kernel<2, 1, 64>, 128, 64); else launch(conv_gemm_bf16x6_kernel<2, 1, 32>, 128, 64); }
+        else { if (deep) launch(conv_gemm_bf16x6_kernel<2, 2, 64>, 128, 128); else launch(conv_gemm_bf16x6_kernel<2, 2, 32>, 128, 128); }
         if (d.split_k > 1)
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(((size_t)d.M * d.N + 255) / 256), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();

@@ -157,8 +157,6 @@ class FlowFormer(ParamTree):
             dec["inp" + sfx] = (torch.cat([parts[g][1] for g in ("z", "r", "q")], 0).contiguous(),
                                 torch.cat([parts[g][2] for g in ("z", "r", "q")], 0).contiguous())
         pk["dec"] = dec
-        if ops.GEMM_PRECISION == 1 and next(iter(p.values())).is_cuda:
-            ops.SPLIT_WEIGHTS.register(("flow", id(self)), ops.collect_2d(pk))
         self._pk = pk
         return pk
 

@@ -72,8 +72,6 @@ class UDIS2Network(ParamTree):
         pk["fc2"] = (p["regressNet1_part2.2.weight"].contiguous(), p["regressNet1_part2.2.bias"].contiguous())
         pk["fc4"] = (p["regressNet1_part2.4.weight"].contiguous(), p["regressNet1_part2.4.bias"].contiguous())
         pk["dev"] = dev
-        if ops.GEMM_PRECISION == 1 and next(iter(p.values())).is_cuda:
-            ops.SPLIT_WEIGHTS.register(("homo", id(self)), ops.collect_2d(pk))
         self._pk = pk
         return pk
 

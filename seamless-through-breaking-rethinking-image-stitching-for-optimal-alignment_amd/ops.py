@@ -46,72 +46,6 @@ _WS = {}
 _WS_OVERRIDE = []
 
 
-class _SplitRegistry:
-    """Static weights split once into three bf16 planes (x = x1 + x2 + x3 exactly) for the bf16x6 GEMM kernel.
-    Looked up by device address, so call sites keep passing the fp32 weight (or a row/column slice of it)."""
-
-    def __init__(self):
-        self.by_owner = {}
-        self.index = []          # sorted (base_ptr, end_ptr, K, planes, src)
-
-    def register(self, owner, tensors):
-        import bisect
-        self.drop(owner)
-        ents = []
-        for w in tensors:
-            if w.dim() != 2 or w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous() or w.shape[1] % 4:
-                continue
-            x1 = w.bfloat16()
-            r1 = w - x1.float()
-            x2 = r1.bfloat16()
-            x3 = (r1 - x2.float()).bfloat16()
-            planes = torch.stack([x1, x2, x3]).contiguous()
-            ents.append((w.data_ptr(), w.data_ptr() + w.numel() * 4, w.shape[1], planes, w))
-        self.by_owner[owner] = ents
-        self.index = sorted((e for es in self.by_owner.values() for e in es), key=lambda e: e[0])
-        self.starts = [e[0] for e in self.index]
-
-    def drop(self, owner):
-        if self.by_owner.pop(owner, None) is not None:
-            self.index = sorted((e for es in self.by_owner.values() for e in es), key=lambda e: e[0])
-            self.starts = [e[0] for e in self.index]
-
-    def find(self, w):
-        """(planes_ptr, ldw, plane_stride) for a registered weight or a slice of one, else None."""
-        import bisect
-        if not self.index:
-            return None
-        ptr = w.data_ptr()
-        i = bisect.bisect_right(self.starts, ptr) - 1
-        if i < 0:
-            return None
-        base, end, K, planes, _ = self.index[i]
-        if not (base <= ptr < end) or w.stride(0) != K:
-            return None
-        off = (ptr - base) // 4
-        if off % 4:
-            return None
-        return planes.data_ptr() + off * 2, K, planes.stride(0)
-
-
-SPLIT_WEIGHTS = _SplitRegistry()
-
-
-def collect_2d(obj, out=None):
-    """all 2-D fp32 tensors inside nested dict / list / tuple containers (weight prepack dictionaries)"""
-    out = [] if out is None else out
-    if torch.is_tensor(obj):
-        if obj.dim() == 2 and obj.dtype == torch.float32:
-            out.append(obj)
-    elif isinstance(obj, dict):
-        for v in obj.values():
-            collect_2d(v, out)
-    elif isinstance(obj, (list, tuple)):
-        for v in obj:
-            collect_2d(v, out)
-    return out
-
-
 def _workspace(dev):
     """split-K slab buffer (64 MiB): one per (device, HIP stream) so concurrent streams never share
     slabs; an execution context that is replayed on arbitrary streams (a captured hipGraph) brings its
@@ -180,11 +114,6 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     d.batch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_c = batch, bsa, bsw, bsc
     d.tile_cfg = tile
     d.precision = GEMM_PRECISION if precision is None else precision
-    if d.precision == 1 and batch <= 1:
-        hit = SPLIT_WEIGHTS.find(w)
-        if hit is not None:
-            d.w, d.ldw, d.w_plane_stride = hit
-            d.w_presplit = 1
     d.split_k = split_k
     if out2 is not None:
         d.c2, d.ldc2 = out2.data_ptr(), _ld(out2)

@@ -22,15 +22,11 @@ x=torch.randn(8192,384,device='cuda'); w=torch.randn(256,5*384,device='cuda')/44
 for prec,c in ((0,c0),(1,c1)):
     ops.conv_gemm(x,w,c,geom=(2,64,64,1,5,1,1,0,2),precision=prec)
 print("conv 1x5 max diff", (c0-c1).abs().max().item(), "time", timeit(lambda: ops.conv_gemm(x,w,c0,geom=(2,64,64,1,5,1,1,0,2),precision=0)), timeit(lambda: ops.conv_gemm(x,w,c1,geom=(2,64,64,1,5,1,1,0,2),precision=1)))
-print("---- pre-split weights")
-for (M,N,K) in [(4096,256,1920),(8192,256,1920),(8192,8192,512),(65536,128,128),(65536,512,128)]:
-    a=torch.randn(M,K,device='cuda'); w=torch.randn(N,K,device='cuda')/K**0.5; c0=torch.empty(M,N,device='cuda'); c1=torch.empty(M,N,device='cuda')
-    ops.SPLIT_WEIGHTS.register("t", [w])
-    ref=(a[:512].double()@w.double().t())
-    ops.conv_gemm(a,w,c1,precision=1,split_k=1)
-    e1=(c1[:512].double()-ref).abs().max().item()
-    t0=timeit(lambda: ops.conv_gemm(a,w,c0,precision=0,split_k=1)); t1=timeit(lambda: ops.conv_gemm(a,w,c1,precision=1,split_k=1))
-    ops.conv_gemm(a[:, 64:],w[64:192, 64:],c1[:, :128],precision=1,split_k=1)
-    e2=(c1[:512,:128].double()-(a[:512, 64:].double()@w[64:192,64:].double().t())).abs().max().item()
-    print(f"M={M} N={N} K={K}: err presplit {e1:.3e} (slice {e2:.3e})  time fp32 {t0:.1f}us ({2*M*N*K/t0/1e6:.1f} TF) presplit {t1:.1f}us ({2*M*N*K/t1/1e6:.1f} TF)")
-    ops.SPLIT_WEIGHTS.drop("t")
+print("---- tiles")
+for (M,N,K) in [(8192,256,1920),(8192,8192,512),(65536,256,1920),(65536,128,128)]:
+    a=torch.randn(M,K,device='cuda'); w=torch.randn(N,K,device='cuda')/K**0.5; c=torch.empty(M,N,device='cuda')
+    r=[]
+    for tile in (3,2,1):
+        t1=timeit(lambda: ops.conv_gemm(a,w,c,precision=1,split_k=1,tile=tile))
+        r.append(f"t{tile}: {t1:.1f}us {2*M*N*K/t1/1e6:.1f}TF")
+    print(f"M={M} N={N} K={K} split: "+"  ".join(r))
