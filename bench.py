@@ -34,34 +34,30 @@ HBM_PEAK_GBS = 8000.0
 
 
 def instrumented_step(model, a, b, ops):
-    """Run one step with a HIP-event pair around every st_conv_gemm launch; return (flops, ms, launches)."""
-    rec = []
-    orig = ops.conv_gemm
+    """Run one step with a HIP-event pair around every st_conv_gemm launch (library observer hook, so the
+    GEMMs enqueued by the operator-level entry points are seen too); return (flops, ms, launches)."""
+    import ctypes as C
+    import stitch_amd
+    lib, GemmDesc = stitch_amd._lib.lib, stitch_amd._lib.GemmDesc
+    rec, open_ev = [], []
 
-    def timed(x, w, out, **kw):
-        geom = kw.get("geom")
-        Cin = x.shape[1]
-        if geom is None:
-            M = kw.get("M") or x.shape[0]
-            K = Cin
+    @C.CFUNCTYPE(None, C.POINTER(GemmDesc), C.c_void_p, C.c_int32, C.c_void_p)
+    def observer(desc, stream, phase, user):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream())
+        if phase == 0:
+            d = desc.contents
+            open_ev.append((2.0 * d.M * d.N * d.K * max(1, d.batch), ev))
         else:
-            B, H, W, kh, kw_, sh, sw, ph, pw = geom[:9]
-            Ho, Wo = ((H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw_) // sw + 1) if len(geom) == 9 else geom[9:11]
-            M, K = B * Ho * Wo, kh * kw_ * Cin
-        flops = 2.0 * M * w.shape[0] * K * max(1, kw.get("batch", 1))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig(x, w, out, **kw)
-        e1.record()
-        rec.append((flops, e0, e1))
-        return r
+            flops, e0 = open_ev.pop()
+            rec.append((flops, e0, ev))
 
-    ops.conv_gemm = timed
+    lib.st_set_gemm_observer(C.cast(observer, C.c_void_p), None)
     try:
         model(a, b, type="test_eval")
         torch.cuda.synchronize()
     finally:
-        ops.conv_gemm = orig
+        lib.st_set_gemm_observer(None, None)
     return sum(f for f, _, _ in rec), sum(e0.elapsed_time(e1) for _, e0, e1 in rec), len(rec)
 
 

@@ -58,6 +58,13 @@ typedef struct st_gemm_desc {
  *   twins.py:253-392,587-680 (q/k/v/proj/sr/MLP), core/UDIS2/Homography/network.py:18-46,103-137. */
 int st_conv_gemm(const st_gemm_desc* desc, void* stream);
 
+/* Profiling observer, off by default: `callback` is a
+ *   void (*)(const st_gemm_desc*, void* stream, int32_t phase, void* user)
+ * invoked on the launching thread before (phase 0) and after (phase 1) every st_conv_gemm enqueues its kernels
+ * (also for the GEMMs launched by the operator-level entry points below), so a caller can bracket them with HIP
+ * events on `stream`.  NULL switches it off.  Process-wide; do not change it while other threads launch.   */
+int st_set_gemm_observer(void* callback, void* user);
+
 /* sizeof(st_gemm_desc) as compiled into the library (binding self-check; returns the size). */
 int st_abi_gemm_desc_size(void);
 
@@ -180,6 +187,39 @@ int st_masked_psnr_ssim(const float* image1, const float* warped, int64_t warped
 /* mean over C planes of x[b] (evaluate.py:45). */
 int st_channel_mean(const float* x, int64_t batch_stride, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
                     void* stream);
+
+/* ---- operator-level entry points (one per reference operator; host-side composition of the kernels
+ *      above on the caller's stream, caller-provided scratch, no allocation, no state) ------------------ */
+/* encode_flow_token with the reference's 9x9 window (decoder.py:242-260).                            */
+int st_cost_lookup9x9(const float* maps, const float* coords, float* out, int32_t ldo, int32_t Nq, int32_t H2,
+                      int32_t W2, void* stream);
+/* warp(x, flow) [* mask] (core/warp_utils.py:54-80, flowHomoAdpater.py:171-172,339-341).             */
+int st_grid_sample_blend(const float* x, const float* flow, const float* mul, float* out, int32_t B, int32_t C,
+                         int32_t H, int32_t W, void* stream);
+/* preprocess_occlusion_mask, 19x19 structuring element (flowHomoAdpater.py:18-35).                   */
+int st_morph_open19(const float* mask, float* out, void* scratch_u8x2, int32_t N, int32_t H, int32_t W,
+                    void* stream);
+/* PatchEmbed.forward (encoder.py:60-95; patch 8, 'single', linear PE): cost maps [M,H,W] -> tokens
+ * [M*P,128], P = ceil(H/8)*ceil(W/8).  weights (host array of 11 device pointers): c0_w[36,16] c0_b
+ * c2_w[32,576] c2_b c4_w[64,1152] c4_b f0_w[128,ld_f0] (cols 0..63) f2_w[128,128] f2_b ln_w ln_b;
+ * pe_bias [P,128] = f0_w[:,64:] . sinePE(pos) + f0_b.  scratch rows: s1 16, s2 32, s3 64, s4 128 wide. */
+int st_patch_embed(const float* cost_maps, const float* const* weights, int32_t ld_f0, const float* pe_bias,
+                   float* s1, float* s2, float* s3, float* s4, float* tokens, int32_t M, int32_t H, int32_t W,
+                   void* workspace, int64_t workspace_floats, void* stream);
+/* GMA Attention.forward (gma.py:54-76), 1 head x 128: attn [B,N,N] = softmax(128^-0.5 q k^T),
+ * [q|k] = inp . w_qk^T (w_qk [256,128]); qk scratch [B*N,256].                                        */
+int st_gma_attention(const float* inp, int32_t ld_inp, const float* w_qk, float* qk, float* attn, int32_t B,
+                     int32_t N, void* workspace, int64_t workspace_floats, void* stream);
+/* GMA Aggregate.forward (gma.py:102-115): out = mf + gamma * attn @ (mf . w_v^T); vT scratch [B,128,N]. */
+int st_gma_aggregate(const float* attn, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma,
+                     float* vT, float* out, int32_t ld_out, int32_t B, int32_t N, void* workspace,
+                     int64_t workspace_floats, void* stream);
+/* SepConvGRU.forward (gru.py:44-59).  hxA rows [h(128) | x(ld-128)], hxB [r*h scratch | same x]; the constant
+ * `inp` channels arrive folded into tab1/tab2 [rows, ld_tab>=384] = conv_inp([z|r|q]) + bias; w_zr* [256,5*ld],
+ * w_q* [128,5*ld] with K ordered (tap, channel); zbuf scratch [rows,128].  h is updated in place in hxA.   */
+int st_sepconv_gru(float* hxA, float* hxB, int32_t ld, float* zbuf, const float* tab1, const float* tab2,
+                   int32_t ld_tab, const float* w_zr1, const float* w_q1, const float* w_zr2, const float* w_q2,
+                   int32_t B, int32_t H, int32_t W, void* workspace, int64_t workspace_floats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -559,8 +559,7 @@ static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
     return ST_OK;
 }
 
-extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
-    if (!desc) return ST_EINVAL;
+static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     st_gemm_desc d = *desc;
     if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
     if (d.kh <= 0 || d.kw <= 0 || d.K != d.kh * d.kw * d.Cin) return ST_EINVAL;
@@ -655,3 +654,27 @@ extern "C" int st_corr_volume(const float* f1, const float* f2, float* vol, int3
 
 // ABI self-check for bindings: size of st_gemm_desc as this library was compiled.
 extern "C" int st_abi_gemm_desc_size(void) { return (int)sizeof(st_gemm_desc); }
+
+
+// Optional profiling observer (bench.py's live roofline): called on the launching thread before (phase 0)
+// and after (phase 1) the kernels of every st_conv_gemm are enqueued -- including the launches made by the
+// operator-level entry points -- so the caller can record HIP events on `stream`.  NULL (default) = off.
+typedef void (*st_gemm_observer_fn)(const st_gemm_desc*, void* stream, int32_t phase, void* user);
+static st_gemm_observer_fn g_observer = nullptr;
+static void* g_observer_user = nullptr;
+
+extern "C" int st_set_gemm_observer(void* callback, void* user) {
+    g_observer = (st_gemm_observer_fn)callback;
+    g_observer_user = user;
+    return ST_OK;
+}
+
+extern "C" int st_conv_gemm(const st_gemm_desc* desc, void* stream) {
+    if (!desc) return ST_EINVAL;
+    st_gemm_observer_fn obs = g_observer;
+    if (!obs) return conv_gemm_launch(desc, stream);
+    obs(desc, stream, 0, g_observer_user);
+    const int rc = conv_gemm_launch(desc, stream);
+    obs(desc, stream, 1, g_observer_user);
+    return rc;
+}

@@ -1,0 +1,156 @@
+// Operator-level entry points: one C symbol per reference operator of the FlowFormer / stitching path
+// (SURVEY.md 8b minimum symbol set).  Host-side composition only: each function enqueues the library's own
+// kernels (gemm.hip, nn.hip, flowops.hip, geom.hip) on the caller's stream, works in caller-provided scratch,
+// allocates nothing and keeps no state.
+#include "common.h"
+#include "../../include/stitch_gfx950.h"
+#include <string.h>
+
+namespace {
+
+struct Gemm {
+    st_gemm_desc d;
+    Gemm(const float* a, int32_t lda, const float* w, int32_t ldw, float* c, int32_t ldc, int32_t M, int32_t N, int32_t Cin) {
+        memset(&d, 0, sizeof(d));
+        d.a = a; d.w = w; d.c = c;
+        d.M = M; d.N = N; d.K = Cin;
+        d.H = 1; d.W = M; d.Cin = Cin; d.ldx = lda;
+        d.kh = d.kw = d.sh = d.sw = 1; d.Ho = 1; d.Wo = M;
+        d.ldw = ldw; d.ldc = ldc;
+        d.alpha = 1.f; d.batch = 1;
+    }
+    Gemm& conv(int32_t B, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw,
+               int32_t Ho = -1, int32_t Wo = -1) {
+        d.H = H; d.W = W; d.kh = kh; d.kw = kw; d.sh = sh; d.sw = sw; d.ph = ph; d.pw = pw;
+        d.Ho = Ho >= 0 ? Ho : (H + 2 * ph - kh) / sh + 1;
+        d.Wo = Wo >= 0 ? Wo : (W + 2 * pw - kw) / sw + 1;
+        d.M = B * d.Ho * d.Wo;
+        d.K = kh * kw * d.Cin;
+        return *this;
+    }
+    Gemm& bias(const float* b) { d.bias = b; return *this; }
+    Gemm& act(int a) { d.act = a; return *this; }
+    Gemm& alpha(float a) { d.alpha = a; return *this; }
+    Gemm& aux0(const float* p, int32_t ld, int32_t row_div = 0, int32_t row_mod = 0) {
+        d.aux0 = p; d.ld_aux0 = ld; d.aux0_row_div = row_div; d.aux0_row_mod = row_mod; return *this;
+    }
+    Gemm& epi(int e, const float* a1, int32_t ld1, const float* a2 = nullptr, int32_t ld2 = 0) {
+        d.epi = e; d.aux1 = a1; d.ld_aux1 = ld1; d.aux2 = a2; d.ld_aux2 = ld2; return *this;
+    }
+    Gemm& scale(const float* s) { d.scale_ptr = s; return *this; }
+    Gemm& out2(float* c2, int32_t ld) { d.c2 = c2; d.ldc2 = ld; return *this; }
+    Gemm& batched(int32_t n, int64_t sa, int64_t sw, int64_t sc) {
+        d.batch = n; d.batch_stride_a = sa; d.batch_stride_w = sw; d.batch_stride_c = sc; return *this;
+    }
+    Gemm& work(void* ws, int64_t floats) { d.workspace = (float*)ws; d.workspace_floats = floats; return *this; }
+    int run(void* stream) { return st_conv_gemm(&d, stream); }
+};
+
+#define ST_TRY(expr)            \
+    do {                        \
+        int rc__ = (expr);      \
+        if (rc__) return rc__;  \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+// encode_flow_token (decoder.py:242-260): the 9x9 (r = 4) window of the reference configuration.
+int st_cost_lookup9x9(const float* maps, const float* coords, float* out, int32_t ldo, int32_t Nq, int32_t H2, int32_t W2,
+                      void* stream) {
+    return st_cost_lookup(maps, coords, out, ldo, Nq, H2, W2, 4, stream);
+}
+
+// warp(x, flow) [* mask] (core/warp_utils.py:54-80 + flowHomoAdpater.py:171-172,339-341).
+int st_grid_sample_blend(const float* x, const float* flow, const float* mul, float* out, int32_t B, int32_t C, int32_t H,
+                         int32_t W, void* stream) {
+    return st_flow_warp(x, flow, mul, out, B, C, H, W, stream);
+}
+
+// preprocess_occlusion_mask with the reference's fixed 19x19 structuring element (flowHomoAdpater.py:18-35).
+int st_morph_open19(const float* mask, float* out, void* scratch_u8x2, int32_t N, int32_t H, int32_t W, void* stream) {
+    return st_morph_open(mask, out, scratch_u8x2, N, H, W, 19, stream);
+}
+
+// PatchEmbed.forward (encoder.py:60-95) for patch_size 8 / 'single' / linear PE:
+//   Conv2d(1,16,6,2,2)+ReLU -> Conv2d(16,32,6,2,2)+ReLU -> Conv2d(32,64,6,2,2) -> [x | sinePE] 1x1 + ReLU -> 1x1 -> LN.
+// The sine half of ffn_with_coord.0 depends on the patch position only, so it arrives as the [P,128] table
+// pe_bias = W0[:,64:] . pe(pos) + b0.  weights (host array of 11 device pointers):
+//   0 c0_w[36,16] 1 c0_b | 2 c2_w[32,576] 3 c2_b | 4 c4_w[64,1152] 5 c4_b | 6 f0_w[128,ld_f0 (cols 0..63 used)]
+//   | 7 f2_w[128,128] 8 f2_b | 9 ln_w 10 ln_b
+// scratch: s1 [M*H/2*W/2,16], s2 [M*H/4*W/4,32], s3 [M*P,64], s4 [M*P,128]; tokens [M*P,128], P = (H/8)*(W/8).
+int st_patch_embed(const float* cost_maps, const float* const* weights, int32_t ld_f0, const float* pe_bias, float* s1,
+                   float* s2, float* s3, float* s4, float* tokens, int32_t M, int32_t H, int32_t W, void* workspace,
+                   int64_t workspace_floats, void* stream) {
+    if (!cost_maps || !weights || !pe_bias || !s1 || !s2 || !s3 || !s4 || !tokens || M <= 0 || H <= 0 || W <= 0)
+        return ST_EINVAL;
+    const int Hp = (H + 7) / 8 * 8, Wp = (W + 7) / 8 * 8;      // zero pad to the patch size (encoder.py:63-66)
+    const int H1 = Hp / 2, W1 = Wp / 2, H2 = Hp / 4, W2 = Wp / 4, H3 = Hp / 8, W3 = Wp / 8, P = H3 * W3;
+    ST_TRY(st_patch_conv1(cost_maps, weights[0], weights[1], s1, M, H, W, H1, W1, stream));
+    ST_TRY(Gemm(s1, 16, weights[2], 576, s2, 32, 0, 32, 16).conv(M, H1, W1, 6, 6, 2, 2, 2, 2, H2, W2)
+               .bias(weights[3]).act(ST_ACT_RELU).work(workspace, workspace_floats).run(stream));
+    ST_TRY(Gemm(s2, 32, weights[4], 1152, s3, 64, 0, 64, 32).conv(M, H2, W2, 6, 6, 2, 2, 2, 2, H3, W3)
+               .bias(weights[5]).work(workspace, workspace_floats).run(stream));
+    ST_TRY(Gemm(s3, 64, weights[6], ld_f0, s4, 128, M * P, 128, 64).aux0(pe_bias, 128, 0, P).act(ST_ACT_RELU)
+               .work(workspace, workspace_floats).run(stream));
+    ST_TRY(Gemm(s4, 128, weights[7], 128, tokens, 128, M * P, 128, 128).bias(weights[8])
+               .work(workspace, workspace_floats).run(stream));
+    return st_layernorm(tokens, 128, weights[9], weights[10], tokens, 128, M * P, 128, 1e-5f, stream);
+}
+
+// GMA Attention.forward (gma.py:54-76), heads = 1, dim_head = 128: attn[b] = softmax(scale * q k^T) with
+// [q | k] = inp . Wqk^T.  qk: scratch [B*N, 256]; attn: [B, N, N].
+int st_gma_attention(const float* inp, int32_t ld_inp, const float* w_qk, float* qk, float* attn, int32_t B, int32_t N,
+                     void* workspace, int64_t workspace_floats, void* stream) {
+    if (!inp || !w_qk || !qk || !attn || B <= 0 || N <= 0 || N > 4096) return ST_EINVAL;
+    ST_TRY(Gemm(inp, ld_inp, w_qk, 128, qk, 256, B * N, 256, 128).work(workspace, workspace_floats).run(stream));
+    ST_TRY(Gemm(qk, 256, qk + 128, 256, attn, N, N, N, 128).alpha(0.08838834764831845f /* 128^-0.5 */)
+               .batched(B, (int64_t)N * 256, (int64_t)N * 256, (int64_t)N * N).run(stream));
+    return st_softmax_rows(attn, N, B * N, N, stream);
+}
+
+// GMA Aggregate.forward (gma.py:102-115), heads = 1: out = mf + gamma * (attn @ (mf . Wv^T)).
+// v is produced transposed (vT[b] = Wv . mf[b]^T, [128, N]) so that attn @ v is again an  A . W^T  contraction.
+// mf/out: rows [B*N, ld] (column slices of the GRU input buffer); vT: scratch [B, 128, N].
+int st_gma_aggregate(const float* attn, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma, float* vT,
+                     float* out, int32_t ld_out, int32_t B, int32_t N, void* workspace, int64_t workspace_floats,
+                     void* stream) {
+    if (!attn || !mf || !w_v || !gamma || !vT || !out || B <= 0 || N <= 0) return ST_EINVAL;
+    for (int b = 0; b < B; ++b) {
+        const float* mfb = mf + (int64_t)b * N * ld_mf;
+        float* vTb = vT + (int64_t)b * 128 * N;
+        ST_TRY(Gemm(w_v, 128, mfb, ld_mf, vTb, N, 128, N, 128).work(workspace, workspace_floats).run(stream));
+        ST_TRY(Gemm(attn + (int64_t)b * N * N, N, vTb, N, out + (int64_t)b * N * ld_out, ld_out, N, 128, N)
+                   .epi(ST_EPI_AXPY, mfb, ld_mf).scale(gamma).work(workspace, workspace_floats).run(stream));
+    }
+    return ST_OK;
+}
+
+// SepConvGRU.forward (gru.py:44-59): horizontal (1x5) then vertical (5x1) gated update of h.
+//   hxA rows [B*H*W, ld] = [h(128) | x(ld-128)], hxB = [r*h scratch(128) | same x]  (x = motion features, already
+//   copied into both); the constant `inp` channels of the reference's hx are folded into the per-pass tables
+//   tab1/tab2 [B*H*W, 384] = conv_inp([z|r|q]) + bias.  Weights: w_zr* [256, 5*ld], w_q* [128, 5*ld], K ordered (tap, c).
+//   z = sigmoid(convz(hx)), r = sigmoid(convr(hx)), q = tanh(convq([r*h, x])), h = (1-z) h + z q.
+int st_sepconv_gru(float* hxA, float* hxB, int32_t ld, float* zbuf, const float* tab1, const float* tab2, int32_t ld_tab,
+                   const float* w_zr1, const float* w_q1, const float* w_zr2, const float* w_q2, int32_t B, int32_t H,
+                   int32_t W, void* workspace, int64_t workspace_floats, void* stream) {
+    if (!hxA || !hxB || !zbuf || !tab1 || !tab2 || !w_zr1 || !w_q1 || !w_zr2 || !w_q2 || ld < 128 || ld_tab < 384 ||
+        B <= 0 || H <= 0 || W <= 0)
+        return ST_EINVAL;
+    const float* tabs[2] = {tab1, tab2};
+    const float* wzr[2] = {w_zr1, w_zr2};
+    const float* wq[2] = {w_q1, w_q2};
+    for (int p = 0; p < 2; ++p) {
+        const int kh = p ? 5 : 1, kw = p ? 1 : 5, ph = p ? 2 : 0, pw = p ? 0 : 2;
+        ST_TRY(Gemm(hxA, ld, wzr[p], 5 * ld, zbuf, 128, 0, 256, ld).conv(B, H, W, kh, kw, 1, 1, ph, pw)
+                   .aux0(tabs[p], ld_tab).act(ST_ACT_SIGMOID).epi(ST_EPI_ZR, hxA, ld).out2(hxB, ld)
+                   .work(workspace, workspace_floats).run(stream));
+        ST_TRY(Gemm(hxB, ld, wq[p], 5 * ld, hxA, ld, 0, 128, ld).conv(B, H, W, kh, kw, 1, 1, ph, pw)
+                   .aux0(tabs[p] + 256, ld_tab).act(ST_ACT_TANH).epi(ST_EPI_GRU, zbuf, 128, hxA, ld)
+                   .work(workspace, workspace_floats).run(stream));
+    }
+    return ST_OK;
+}
+
+}  // extern "C"

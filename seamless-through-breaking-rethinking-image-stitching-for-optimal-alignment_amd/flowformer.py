@@ -88,6 +88,8 @@ class FlowFormer(ParamTree):
                   f0=conv(c + "patch_embed.ffn_with_coord.0"), f2=conv(c + "patch_embed.ffn_with_coord.2"),
                   norm=lin(c + "patch_embed.norm"))
         pe["c0_direct"] = (p[c + "patch_embed.proj.0.weight"].reshape(16, 36).t().contiguous(), pe["c0"][1])
+        pe["embed11"] = [pe["c0_direct"][0], pe["c0_direct"][1], pe["c2"][0], pe["c2"][1], pe["c4"][0], pe["c4"][1],
+                         pe["f0"][0], pe["f2"][0], pe["f2"][1], pe["norm"][0], pe["norm"][1]]
         pk["pe"] = pe
         pk["latents"] = p[c + "latent_tokens"][0].contiguous()
 
@@ -226,17 +228,7 @@ class FlowFormer(ParamTree):
         pe = self._pk["pe"]
         dev = cost_maps.device
         Hp, Wp = (H2 + 7) // 8 * 8, (W2 + 7) // 8 * 8           # zero-pad to a multiple of the patch size (:63-66)
-        h, w = H2, W2
-        x = cost_maps.view(M * H2 * W2, 1)
-        for name, co in (("c0", 16), ("c2", 32), ("c4", 64)):
-            Hp, Wp = Hp // 2, Wp // 2
-            y = _new(M * Hp * Wp, co, dev)
-            if name == "c0":
-                ops.patch_conv1(cost_maps, pe["c0_direct"][0], pe["c0_direct"][1], y, M, h, w, Hp, Wp)
-            else:
-                ops.conv_gemm(x, pe[name][0], y, geom=(M, h, w, 6, 6, 2, 2, 2, 2, Hp, Wp), bias=pe[name][1],
-                              act="relu" if name != "c4" else "none")
-            x, h, w = y, Hp, Wp
+        H1, W1, H2p, W2p, h, w = Hp // 2, Wp // 2, Hp // 4, Wp // 4, Hp // 8, Wp // 8
         P = h * w
         key = ("pe_tab", h, w)
         if key not in self._const:
@@ -247,11 +239,9 @@ class FlowFormer(ParamTree):
             tab = _new(P, 128, dev)
             ops.conv_gemm(tab_in, pe["f0"][0][:, 64:], tab, bias=pe["f0"][1])
             self._const[key] = tab
-        f = _new(M * P, 128, dev)
-        ops.conv_gemm(x, pe["f0"][0][:, :64], f, aux0=self._const[key], row_mod=P, act="relu")
-        f2 = _new(M * P, 128, dev)
-        ops.conv_gemm(f, pe["f2"][0], f2, bias=pe["f2"][1])
-        ops.layernorm(f2, pe["norm"][0], pe["norm"][1], f, 1e-5)
+        s1, s2 = _new(M * H1 * W1, 16, dev), _new(M * H2p * W2p, 32, dev)
+        s3, s4, f = _new(M * P, 64, dev), _new(M * P, 128, dev), _new(M * P, 128, dev)
+        ops.patch_embed(cost_maps, pe["embed11"], pe["f0"][0].stride(0), self._const[key], s1, s2, s3, s4, f, M, H2, W2)
         return f, P
 
     def _latent_layer(self, L, x, M, first, tokens=None, P=0):
@@ -408,11 +398,8 @@ class FlowFormer(ParamTree):
             ops.conv_gemm(inp, D["inp" + sfx][0], gru_tab[sfx], geom=gru_geom[sfx], bias=D["inp" + sfx][1])
         # GMA attention, once (gma.py:54-76)
         qk = _new(R, 256, dev)
-        ops.conv_gemm(inp, D["qk"], qk)
         attn = torch.empty((B, N, N), device=dev)
-        ops.conv_gemm(qk[:N, :128], qk[:N, 128:], attn.view(B * N, N), alpha=128 ** -0.5, batch=B, bsa=N * 256,
-                      bsw=N * 256, bsc=N * N)
-        ops.softmax_rows(attn.view(B * N, N))
+        ops.gma_attention(inp, D["qk"], qk, attn, B, N)
         # k, v of the cost-memory cross attention, once (decoder.py:68-70); memory = x + short_cut (linear -> two GEMMs)
         ca = D["ca"]
         kv0 = _new(R * nl, 128, dev)
@@ -428,7 +415,7 @@ class FlowFormer(ParamTree):
         zbuf, fh = _new(R, 128, dev), _new(R, 256, dev)
         g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
         for it in range(iters):
-            ops.cost_lookup(cost_maps, coords1, corr, R, H1, W1, 4)                                   # decoder.py:291
+            ops.cost_lookup9x9(cost_maps, coords1, corr, R, H1, W1)                                   # decoder.py:291
             # flow_token_encoder + cost-memory cross attention + FFN: one fused launch (decoder.py:305-312)
             ops.decoder_token_chain(corr, coords1, kv, D["chain16"], R, nl)
             ops.flow_from_coords(coords1, flow4, hxA[:, 254:256], B, H1, W1)                          # :321, gru.py:254
@@ -439,18 +426,10 @@ class FlowFormer(ParamTree):
             ops.conv_gemm(flo1, D["convf2"][0], corflo[:, 192:], geom=g3, bias=D["convf2"][1], act="relu")
             ops.conv_gemm(corflo, D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu")
             # GMA aggregate (gma.py:102-115): v^T = Wv . mf^T, out = mf + gamma * attn @ v
-            for b in range(B):
-                rows = slice(b * N, (b + 1) * N)
-                ops.conv_gemm(D["to_v"], hxA[rows, 128:256], vT[b])
-                ops.conv_gemm(attn[b], vT[b], hxA[rows, 256:], epi="axpy", aux1=hxA[rows, 128:256], scale_ptr=D["gamma"])
+            ops.gma_aggregate(attn, hxA[:, 128:256], D["to_v"], D["gamma"], vT, hxA[:, 256:], B, N)
             ops.copy2d(hxA[:, 128:], hxB[:, 128:])
             # SepConvGRU (gru.py:44-59): horizontal 1x5 then vertical 5x1
-            for sfx in ("1", "2"):
-                gg, tab = gru_geom[sfx], gru_tab[sfx]
-                ops.conv_gemm(hxA, D["zr" + sfx], zbuf, geom=gg, aux0=tab[:, :256], act="sigmoid", epi="zr",
-                              aux1=hxA[:, :128], out2=hxB[:, :128])                                   # z ; r*h
-                ops.conv_gemm(hxB, D["q" + sfx], hxA[:, :128], geom=gg, aux0=tab[:, 256:], act="tanh", epi="gru",
-                              aux1=zbuf, aux2=hxA[:, :128])                                           # h = (1-z)h + z q
+            ops.sepconv_gru(hxA, hxB, zbuf, gru_tab["1"], gru_tab["2"], D["zr1"], D["q1"], D["zr2"], D["q2"], B, H1, W1)
             # flow head (gru.py:5-13) and coords1 += delta_flow (decoder.py:329)
             ops.conv_gemm(hxA[:, :128], D["fh1"][0], fh, geom=g3, bias=D["fh1"][1], act="relu")
             ops.conv_gemm(fh, D["fh2"][0], coords1, geom=g3, bias=D["fh2"][1], epi="add", aux1=coords1)

@@ -224,6 +224,50 @@ def decoder_token_chain(corr, coords1, kv, weights16, rows, ntok):
     return corr
 
 
+# ---- operator-level entry points (csrc/operators.hip) -------------------------------------------
+def _ws(dev):
+    ws = _workspace(dev)
+    return ws.data_ptr(), ws.numel()
+
+
+def cost_lookup9x9(maps, coords, out, Nq, H2, W2):
+    check(lib.st_cost_lookup9x9(_p(maps), _pc(coords), _p(out), _ld(out), Nq, H2, W2, _stream()), "st_cost_lookup9x9")
+    return out
+
+
+def patch_embed(cost_maps, weights11, ld_f0, pe_bias, s1, s2, s3, s4, tokens, M, H, W):
+    arr = (C.c_void_p * 11)(*[w.data_ptr() for w in weights11])
+    check(lib.st_patch_embed(_pc(cost_maps), arr, ld_f0, _pc(pe_bias), _pc(s1), _pc(s2), _pc(s3), _pc(s4), _pc(tokens),
+                             M, H, W, *_ws(cost_maps.device), _stream()), "st_patch_embed")
+    return tokens
+
+
+def gma_attention(inp, w_qk, qk, attn, B, N):
+    check(lib.st_gma_attention(_p(inp), _ld(inp), _pc(w_qk), _pc(qk), _pc(attn), B, N, *_ws(inp.device), _stream()),
+          "st_gma_attention")
+    return attn
+
+
+def gma_aggregate(attn, mf, w_v, gamma, vT, out, B, N):
+    check(lib.st_gma_aggregate(_pc(attn), _p(mf), _ld(mf), _pc(w_v), _p(gamma), _pc(vT), _p(out), _ld(out), B, N,
+                               *_ws(mf.device), _stream()), "st_gma_aggregate")
+    return out
+
+
+def sepconv_gru(hxA, hxB, zbuf, tab1, tab2, w_zr1, w_q1, w_zr2, w_q2, B, H, W):
+    assert _ld(hxA) == _ld(hxB) and w_zr1.shape[1] == 5 * _ld(hxA)
+    check(lib.st_sepconv_gru(_p(hxA), _p(hxB), _ld(hxA), _pc(zbuf), _p(tab1), _p(tab2), _ld(tab1), _pc(w_zr1), _pc(w_q1),
+                             _pc(w_zr2), _pc(w_q2), B, H, W, *_ws(hxA.device), _stream()), "st_sepconv_gru")
+    return hxA
+
+
+def grid_sample_blend(x, flow, mul, out):
+    B, Cc, H, W = x.shape
+    check(lib.st_grid_sample_blend(_pc(x), _pc(flow), _pc(mul) if mul is not None else None, _pc(out), B, Cc, H, W,
+                                   _stream()), "st_grid_sample_blend")
+    return out
+
+
 def convex_upsample(coords1, mask, out, B, H, W):
     check(lib.st_convex_upsample(_p(coords1), _p(mask), _ld(mask), _p(out), B, H, W, _stream()), "st_convex_upsample")
     return out
@@ -262,7 +306,7 @@ def mesh_bounds(H, out4, width, height, gw=511, gh=511):
 def flow_warp(x, flow, mul=None):
     B, Cc, H, W = x.shape
     out = torch.empty_like(x)
-    check(lib.st_flow_warp(_pc(x), _pc(flow), _pc(mul), _p(out), B, Cc, H, W, _stream()), "st_flow_warp")
+    check(lib.st_grid_sample_blend(_pc(x), _pc(flow), _pc(mul), _p(out), B, Cc, H, W, _stream()), "st_grid_sample_blend")
     return out
 
 
@@ -293,7 +337,10 @@ def morph_open(mask, ksz=19):
     B, Cc, H, W = mask.shape
     scratch = torch.empty((2 * B * Cc * H * W,), device=mask.device, dtype=torch.uint8)
     out = torch.empty_like(mask)
-    check(lib.st_morph_open(_pc(mask), _p(out), _p(scratch), B * Cc, H, W, ksz, _stream()), "st_morph_open")
+    if ksz == 19:
+        check(lib.st_morph_open19(_pc(mask), _p(out), _p(scratch), B * Cc, H, W, _stream()), "st_morph_open19")
+    else:
+        check(lib.st_morph_open(_pc(mask), _p(out), _p(scratch), B * Cc, H, W, ksz, _stream()), "st_morph_open")
     return out
 
 

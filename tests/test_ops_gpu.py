@@ -475,3 +475,97 @@ def test_decoder_token_chain_fused(ops, seeded_sd):
     ops.decoder_token_chain(corr, nhwc(coords), kv, ws, R, nl)
     assert (corr[:, 84:].cpu() - ref).abs().max() < 1e-4, (corr[:, 84:].cpu() - ref).abs().max()
     assert torch.equal(corr[:, :81].cpu(), cf.permute(0, 2, 3, 1).reshape(R, 81))
+
+
+# ---------------------------------------------------------------- operator-level entry points (csrc/operators.hip)
+def test_gma_attention_and_aggregate_operators(ops):
+    """st_gma_attention / st_gma_aggregate against gma.py:54-76,102-115 written with stock fp64 torch ops."""
+    B, H, W = 2, 12, 16
+    N = H * W
+    inp = torch.randn(B, 128, H, W, generator=g(1))
+    mf = torch.randn(B, 128, H, W, generator=g(2))
+    w_qk = torch.randn(256, 128, generator=g(3)) / 128 ** 0.5
+    w_v = torch.randn(128, 128, generator=g(4)) / 128 ** 0.5
+    gamma = torch.tensor([0.37])
+    x = inp.double().flatten(2).transpose(1, 2)                              # [B,N,128]
+    q, k = (x @ w_qk.double().t()).chunk(2, dim=-1)
+    attn_ref = torch.softmax(128 ** -0.5 * q @ k.transpose(1, 2), dim=-1)
+    m = mf.double().flatten(2).transpose(1, 2)
+    out_ref = m + gamma.double() * (attn_ref @ (m @ w_v.double().t()))
+    wide = torch.zeros(B * N, 384, device="cuda")                            # [h | mf | mf_global] like the GRU input rows
+    wide[:, 128:256] = nhwc(mf)
+    qk = torch.empty(B * N, 256, device="cuda")
+    attn = torch.empty(B, N, N, device="cuda")
+    ops.gma_attention(nhwc(inp), dev(w_qk), qk, attn, B, N)
+    assert (attn.cpu().double() - attn_ref).abs().max() < 1e-6
+    vT = torch.empty(B, 128, N, device="cuda")
+    ops.gma_aggregate(attn, wide[:, 128:256], dev(w_v), dev(gamma), vT, wide[:, 256:], B, N)
+    got = wide[:, 256:].cpu().double().view(B, N, 128)
+    assert (got - out_ref).abs().max() < 2e-5 * out_ref.abs().max()
+    assert torch.equal(wide[:, :128].cpu(), torch.zeros(B * N, 128))         # neighbours untouched
+
+
+def test_sepconv_gru_operator(ops):
+    """st_sepconv_gru against SepConvGRU.forward (gru.py:44-59) written with stock torch convs (fp64)."""
+    B, H, W = 2, 12, 16
+    R = B * H * W
+    h0 = torch.randn(B, 128, H, W, generator=g(1)).tanh()
+    inp = torch.randn(B, 128, H, W, generator=g(2)).relu()
+    x = torch.randn(B, 256, H, W, generator=g(3))
+    wts = {}
+    for i, name in enumerate(("z1", "r1", "q1", "z2", "r2", "q2")):
+        k = (1, 5) if name.endswith("1") else (5, 1)
+        wts[name] = (torch.randn(128, 512, *k, generator=g(10 + i)) * 0.02, torch.randn(128, generator=g(20 + i)) * 0.1)
+    h = h0.double()
+    for s, pad in (("1", (0, 2)), ("2", (2, 0))):
+        cv = lambda t, n: F.conv2d(t, wts[n][0].double(), wts[n][1].double(), padding=pad)   # noqa: E731
+        hx = torch.cat([h, inp.double(), x.double()], 1)
+        z, r = torch.sigmoid(cv(hx, "z" + s)), torch.sigmoid(cv(hx, "r" + s))
+        q = torch.tanh(cv(torch.cat([r * h, inp.double(), x.double()], 1), "q" + s))
+        h = (1 - z) * h + z * q
+
+    def pack_hx(w):                      # drop the constant `inp` channels, K ordered (tap, channel)
+        return pack_conv_w(torch.cat([w[:, :128], w[:, 256:]], 1))
+
+    def table(s, pad):                   # conv over `inp` + bias for [z | r | q]
+        return nhwc(torch.cat([F.conv2d(inp, wts[n + s][0][:, 128:256], wts[n + s][1], padding=pad) for n in "zrq"], 1))
+
+    hxA, hxB = torch.zeros(R, 384, device="cuda"), torch.zeros(R, 384, device="cuda")
+    hxA[:, :128], hxA[:, 128:], hxB[:, 128:] = nhwc(h0), nhwc(x), nhwc(x)
+    zbuf = torch.empty(R, 128, device="cuda")
+    ops.sepconv_gru(hxA, hxB, zbuf, table("1", (0, 2)), table("2", (2, 0)),
+                    torch.cat([pack_hx(wts["z1"][0]), pack_hx(wts["r1"][0])]), pack_hx(wts["q1"][0]),
+                    torch.cat([pack_hx(wts["z2"][0]), pack_hx(wts["r2"][0])]), pack_hx(wts["q2"][0]), B, H, W)
+    got = from_rows(hxA[:, :128], B, H, W).double()
+    assert (got - h).abs().max() < 2e-5, (got - h).abs().max()
+    assert torch.equal(hxA[:, 128:].cpu(), nhwc(x).cpu())
+
+
+def test_patch_embed_operator_ragged(ops):
+    """st_patch_embed on a cost map whose side is not a multiple of 8 (zero pad, encoder.py:63-66) vs torch fp64."""
+    M, H, W = 5, 12, 20
+    cm = torch.randn(M, 1, H, W, generator=g(1))
+    mk = lambda *s, sc=0.1, seed=0: torch.randn(*s, generator=g(seed)) * sc          # noqa: E731
+    c0, b0, c2, b2, c4, b4 = mk(16, 1, 6, 6, seed=2), mk(16, seed=3), mk(32, 16, 6, 6, seed=4, sc=0.05), mk(32, seed=5), \
+        mk(64, 32, 6, 6, seed=6, sc=0.03), mk(64, seed=7)
+    f0, fb0, f2, fb2, lw, lb = mk(128, 128, seed=8), mk(128, seed=9), mk(128, 128, seed=10), mk(128, seed=11), \
+        1 + mk(128, seed=12), mk(128, seed=13)
+    Hp, Wp = (H + 7) // 8 * 8, (W + 7) // 8 * 8
+    x = F.pad(cm.double(), (0, Wp - W, 0, Hp - H))
+    x = F.relu(F.conv2d(x, c0.double(), b0.double(), stride=2, padding=2))
+    x = F.relu(F.conv2d(x, c2.double(), b2.double(), stride=2, padding=2))
+    x = F.conv2d(x, c4.double(), b4.double(), stride=2, padding=2)
+    h, w = x.shape[-2:]
+    P = h * w
+    pe_in = torch.zeros(P, 64, device="cuda")
+    ops.sine_pe(pe_in, 64, Wg=w, cscale=8.0, coff=4.0)                               # encoder.py:77-80 (own parity test above)
+    tok = torch.cat([x.flatten(2).transpose(1, 2), pe_in.cpu().double()[None].expand(M, P, 64)], -1)
+    tok = F.relu(tok @ f0.double().t() + fb0.double()) @ f2.double().t() + fb2.double()
+    ref = F.layer_norm(tok, (128,), lw.double(), lb.double(), 1e-5)
+    pe_bias = (pe_in.cpu() @ f0[:, 64:].t() + fb0).cuda().contiguous()
+    w11 = [dev(c0.reshape(16, 36).t()), dev(b0), pack_conv_w(c2), dev(b2), pack_conv_w(c4), dev(b4), dev(f0), dev(f2), dev(fb2),
+           dev(lw), dev(lb)]
+    s1, s2 = torch.empty(M * (Hp // 2) * (Wp // 2), 16, device="cuda"), torch.empty(M * (Hp // 4) * (Wp // 4), 32, device="cuda")
+    s3, s4, out = torch.empty(M * P, 64, device="cuda"), torch.empty(M * P, 128, device="cuda"), torch.empty(M * P, 128, device="cuda")
+    ops.patch_embed(dev(cm.reshape(M, H * W)), w11, 128, pe_bias, s1, s2, s3, s4, out, M, H, W)
+    assert (out.cpu().double().view(M, P, 128) - ref).abs().max() < 1e-4
