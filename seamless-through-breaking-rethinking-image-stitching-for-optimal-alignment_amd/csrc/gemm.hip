@@ -343,6 +343,245 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Deep-pipelined variant of the same contraction: operand tiles go global -> LDS directly
+// (buffer_load_dwordx4 ... lds, no VGPR staging, no ds_write), STAGES tiles deep, one raw s_barrier per
+// K step with a counted s_waitcnt vmcnt so that STAGES-2 tiles stay in flight across every barrier.
+// This is what keeps a workgroup's MFMAs fed when it is alone on its CU (the M = 8192 decoder GEMMs launch
+// 256..512 workgroups): the register-staged kernel above can hold one tile in flight, whose L2 latency is
+// longer than the 16 MFMAs of a K step.
+//   LDS image of a stage: (BM + BN) rows x 128 B (32 k), unpadded -- one DMA wave-instruction writes 1 KiB
+//   = 8 whole rows, lane l -> row l/8, 16-B slot l%8.  Bank conflicts are avoided by an XOR swizzle applied
+//   on the SOURCE side: slot s of row r holds k-chunk s ^ ((r >> 1) & 7); the fragment reads
+//   (32 rows x one chunk per ds_read_b128) then hit 16 distinct bank quads in each hardware lane group.
+//   Out-of-image taps use an offset past the descriptor's num_records: the DMA writes zeros (probed on gfx950).
+//   The DMA is issued from inline asm: hipcc treats the builtin form as a pending LDS write and puts
+//   s_waitcnt vmcnt(0) in front of the next ds_read, which would drain the whole pipeline every K step.
+// Preconditions (checked by the host): 16-B aligned operands, Cin % 32 == 0 (a K step never straddles taps).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct st_true { static constexpr bool value = true; };
+struct st_false { static constexpr bool value = false; };
+
+// M0 is not used by anything else in these kernels (gfx9 DS ops do not need it), so it is simply overwritten.
+__device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory");
+}
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));   // stride 0, no swizzle
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// The K loop is written around one measured fact (tools/mfma_gap: v_mfma_f32_32x32x2_f32 shares the fp32 FMA
+// datapath with the VALU): every VALU instruction issued between two MFMAs costs 4-8 cycles of matrix time
+// (2 VALU per MFMA: 67 -> 89 cycles per MFMA at one wave per SIMD), while SALU (<= 4 per MFMA), ds_read and
+// buffer_load...lds issue for free.  So the loop body contains NO per-tile VALU work:
+//   - fragment reads use loop-invariant address VGPRs + immediate offsets (the loop is unrolled by STAGES so the
+//     stage offset is a literal);
+//   - DMA source addresses are loop-invariant VGPR offsets + an SGPR offset advanced on the SALU; the only VALU
+//     left is the padding test, redone when the (ky, kx) tap changes (every Cin/32 tiles), never for 1x1;
+//   - waits, barrier, loop control are scalar.
+template <int TM, int TN, int STAGES>
+__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d) {
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, ROWS = BM + BN;
+    constexpr int PA = BM / 32, PB = BN / 32;      // 1-KiB pieces (8 rows x 128 B) per wave and K step
+    constexpr int PPW = PA + PB;
+    constexpr int STAGE_FLOATS = ROWS * 32;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int split = d.split_k > 1 ? d.split_k : 1;
+    const int bz = split > 1 ? 0 : blockIdx.z;
+    const int kz = split > 1 ? blockIdx.z : 0;
+    const float* __restrict__ X = d.a + (size_t)bz * d.batch_stride_a;
+    const float* __restrict__ Wt = d.w + (size_t)bz * d.batch_stride_w;
+    float* __restrict__ C = d.c + (size_t)bz * d.batch_stride_c;
+
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % ntn, tile_m = bid / ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const i32x4 rsrcA = make_rsrc(X, d.a_bytes), rsrcW = make_rsrc(Wt, d.w_bytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;   // LDS byte address
+
+    // staging slots of this lane: wave w stages A rows [8*PA*w, 8*PA*(w+1)) and B rows [8*PB*w, 8*PB*(w+1)),
+    // 8 rows per piece, lane l -> row l/8 of the piece, 16-B slot l%8 holding k-chunk (l%8) ^ ((row>>1)&7)
+    int a_base[PA], a_iy0[PA], a_ix0[PA];
+    unsigned voffA[PA], voffB[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int r = 8 * (wave * PA + i) + (lane >> 3);
+        const int chunk4 = (((lane & 7) ^ ((r >> 1) & 7)) << 2);
+        const int m = min(m0 + r, d.M - 1);                                 // rows past M: any valid row (never stored)
+        const int hw = d.Ho * d.Wo;
+        const int b = m / hw, rr = m - b * hw;
+        const int oy = rr / d.Wo, ox = rr - oy * d.Wo;
+        a_iy0[i] = oy * d.sh - d.ph; a_ix0[i] = ox * d.sw - d.pw;
+        a_base[i] = ((b * d.H + a_iy0[i]) * d.W + a_ix0[i]) * d.ldx + chunk4;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int r = 8 * (wave * PB + i) + (lane >> 3);                    // row inside the B part; BM % 16 == 0
+        const int chunk4 = (((lane & 7) ^ ((r >> 1) & 7)) << 2);
+        voffB[i] = (unsigned)(min(n0 + r, d.N - 1) * d.ldw + chunk4) * 4u;
+    }
+
+    const int nkt_all = d.K / 32;
+    const int per = (nkt_all + split - 1) / split;
+    const int kt0 = kz * per;
+    const int ntiles = min(nkt_all, kt0 + per) - kt0;
+
+    // wave-uniform state of the next tile to issue: tap (ky, kx), channel offset c0; byte offsets for the SGPR operand
+    int i_c0, i_ky, i_kx;
+    {
+        const int k = kt0 * 32, tap = k / d.Cin;
+        i_c0 = k - tap * d.Cin; i_ky = tap / d.kw; i_kx = tap - i_ky * d.kw;
+    }
+    unsigned soffA = (unsigned)i_c0 * 4u, soffB = (unsigned)kt0 * 128u;
+    auto set_tap = [&]() {                          // per-lane source offsets of the A pieces for tap (i_ky, i_kx)
+        const int tapbase = (i_ky * d.W + i_kx) * d.ldx;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const bool ok = (unsigned)(a_iy0[i] + i_ky) < (unsigned)d.H && (unsigned)(a_ix0[i] + i_kx) < (unsigned)d.W;
+            voffA[i] = ok ? (unsigned)(a_base[i] + tapbase) * 4u : ST_OOB;
+        }
+    };
+    set_tap();
+    auto issue_a = [&](int stage, int i) {
+        lds_dma16(rsrcA, lds0 + (unsigned)(stage * STAGE_FLOATS + (wave * PA + i) * 256) * 4u, voffA[i], soffA);
+    };
+    auto issue_b = [&](int stage, int i) {
+        lds_dma16(rsrcW, lds0 + (unsigned)(stage * STAGE_FLOATS + BM * 32 + (wave * PB + i) * 256) * 4u, voffB[i], soffB);
+    };
+    auto advance = [&]() {                          // scalar, except the padding test when the tap changes
+        soffB += 128u; soffA += 128u; i_c0 += 32;
+        if (i_c0 >= d.Cin) {
+            i_c0 = 0; soffA = 0;
+            if (++i_kx == d.kw) { i_kx = 0; ++i_ky; }
+            set_tap();
+        }
+    };
+    // wait until at most `tiles` whole tiles of this wave's DMA pieces are still in flight (wave-uniform)
+    auto wait_tiles = [&](int tiles) {
+        if (tiles >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int swz = (li >> 1) & 7;
+    // loop-invariant fragment pointers (one per 8-k step: the XOR swizzle is lane dependent); stage / sub-tile
+    // offsets are literals folded into the ds_read offset field
+    const float* pa[4];
+    const float* pb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int foff = ((2 * j + lh) ^ swz) << 2;
+        pa[j] = smem + (wm * TM * 32 + li) * 32 + foff;
+        pb[j] = smem + (BM + wn * TN * 32 + li) * 32 + foff;
+    }
+
+    float4 fa[2][TM], fb[2][TN];                   // fragment ping-pong: step j+1 is read under the MFMAs of step j
+    auto read_frags = [&](int buf, int stage, int j) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[buf][i] = *reinterpret_cast<const float4*>(pa[j] + stage * STAGE_FLOATS + i * 1024);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fb[buf][i] = *reinterpret_cast<const float4*>(pb[j] + stage * STAGE_FLOATS + i * 1024);
+    };
+    auto comp = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+    auto mfma_k = [&](int buf, int e) {            // the TM*TN MFMAs of one k (k = 8j + 4*lane_half + e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[buf][i], e), comp(fb[buf][jn], e), acc[i][jn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define ST_GAP(stmt) do { stmt; __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    if (ntiles > 0) {
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < ntiles) {
+#pragma unroll
+                for (int i = 0; i < PA; ++i) issue_a(t, i);
+#pragma unroll
+                for (int i = 0; i < PB; ++i) issue_b(t, i);
+                advance();
+            }
+        wait_tiles(min(STAGES - 2, ntiles - 1));    // tile 0 landed (this wave's pieces) ...
+        asm volatile("s_barrier" ::: "memory");     // ... and everybody else's
+        read_frags(0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // one tile: stage s (literal), tile index t.  FULL = steady state (tile t+STAGES-1 exists): no branches at all.
+        auto tile_body = [&](auto full_c, int s, int t) {
+            constexpr bool FULL = decltype(full_c)::value;
+            const bool more = FULL || t + 1 < ntiles, feed = FULL || t + STAGES - 1 < ntiles;
+            const int fstage = (s + STAGES - 1) % STAGES, nstage = (s + 1) % STAGES;
+            // ---- k-step 0 (fragments in buffer 0)
+            mfma_k(0, 0); ST_GAP(read_frags(1, s, 1));
+            mfma_k(0, 1);
+            // tile t+1 has landed everywhere and every wave is past tile t-1, whose stage is therefore free
+            if (FULL) ST_GAP(wait_tiles(STAGES - 3); asm volatile("s_barrier" ::: "memory"));
+            else ST_GAP(if (more) { wait_tiles(min(STAGES - 3, ntiles - 2 - t)); asm volatile("s_barrier" ::: "memory"); });
+            mfma_k(0, 2); ST_GAP(if (feed) issue_a(fstage, 0));
+            mfma_k(0, 3); ST_GAP(if (feed) { _Pragma("unroll") for (int i = 1; i < PA; ++i) issue_a(fstage, i); });
+            // ---- k-step 1 (buffer 1)
+            mfma_k(1, 0); ST_GAP(read_frags(0, s, 2));
+            mfma_k(1, 1); ST_GAP(if (feed) issue_b(fstage, 0));
+            mfma_k(1, 2); ST_GAP(if (feed) { _Pragma("unroll") for (int i = 1; i < PB; ++i) issue_b(fstage, i); });
+            mfma_k(1, 3); ST_GAP(if (feed) advance());
+            // ---- k-step 2 (buffer 0)
+            mfma_k(0, 0); ST_GAP(read_frags(1, s, 3));
+            mfma_k(0, 1); mfma_k(0, 2); mfma_k(0, 3);
+            // ---- k-step 3 (buffer 1); step 0 of the next tile is read under it (a stale read after the last tile)
+            mfma_k(1, 0); ST_GAP(read_frags(0, nstage, 0));
+            mfma_k(1, 1); mfma_k(1, 2); mfma_k(1, 3);
+        };
+        int tb = 0;
+        for (; tb + 2 * STAGES - 1 <= ntiles; tb += STAGES) {           // every tile of the block still feeds a new one
+#pragma unroll
+            for (int s = 0; s < STAGES; ++s) tile_body(st_true{}, s, tb + s);
+        }
+        for (; tb < ntiles; tb += STAGES) {
+#pragma unroll
+            for (int s = 0; s < STAGES; ++s)
+                if (tb + s < ntiles) tile_body(st_false{}, s, tb + s);
+        }
+    }
+#undef ST_GAP
+
+    gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp32 GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand value is split EXACTLY into three bf16 parts
 // (x = x1 + x2 + x3, 8 significant bits each) and the product keeps the six partial products of order <= 2^-16
 // (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2) accumulated in fp32.  The dropped terms are <= 2^-23 relative -- below fp32's
@@ -559,6 +798,21 @@ static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
     return ST_OK;
 }
 
+template <int TM, int TN, int STAGES>
+static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : (d.batch > 0 ? d.batch : 1));
+    const size_t lds = (size_t)STAGES * (BM + BN) * 32 * sizeof(float);
+    auto k = conv_gemm_dma_kernel<TM, TN, STAGES>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, d);
+    if (d.split_k > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(((size_t)d.M * d.N + 255) / 256), dim3(256), 0, s, d);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     st_gemm_desc d = *desc;
     if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
@@ -587,24 +841,35 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     // tile choice: largest tile that still yields >= ~1.5 waves of workgroups over the 256 CUs
     auto nwg = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };
     int cfg = d.tile_cfg;
+    // the LDS-DMA pipelined kernel needs whole 32-channel K steps inside one tap; K < 256 (<= 8 steps) is all
+    // prologue / epilogue and gains nothing from it
+    const bool dma_ok = aligned && d.Cin % 32 == 0;
     if (cfg == 0) {
-        // measured on MI355X (tools/tile_sweep.py): the 64x64 tile wins for every short-K / mid-size shape of
-        // this path (more resident workgroups hide the load->LDS->MFMA latency); the 128-wide tiles only pay
-        // once K is long and the grid still covers the chip several times over.
+        // measured on MI355X (tools/tile_sweep.py, tools/dma_sweep.py): the 64x64 tile wins for every short-K /
+        // mid-size shape of this path (more resident workgroups); 128-wide tiles stay selectable through tile_cfg.
         if (d.N <= 32) cfg = 4;
-        else cfg = 3;      // 1 (128x128) and 2 (128x64) stay selectable through tile_cfg
+        else cfg = (dma_ok && d.K >= 256 && d.precision == 0) ? 13 : 3;
     }
+    if (cfg > 10 && !dma_ok) return ST_EINVAL;
     // split-K: a launch that cannot fill the 256 CUs (M = 4096-pixel maps x 64..256 channels) is cut
     // along K into slabs reduced by a second tiny kernel (deterministic order; no atomics).
     static const int bms[5] = {0, 128, 128, 64, 128}, bns[5] = {0, 128, 64, 64, 32};
-    const long tiles = nwg(bms[cfg], bns[cfg]);
+    const long tiles = cfg > 10 ? nwg(bms[cfg - 10], bns[cfg - 10]) : nwg(bms[cfg], bns[cfg]);
     int split = d.split_k;
     if (split == 0) {
         split = 1;
-        if (batch == 1 && d.workspace && tiles < 256 && d.K >= 512) {
-            split = (int)((512 + tiles - 1) / tiles);
+        if (batch == 1 && d.workspace && d.K >= 512) {
+            if (cfg > 10) {
+                // the pipelined kernel runs near its steady-state rate with ONE workgroup per CU, so it only needs
+                // every CU covered; 257..511 tiles leave half the chip with twice the work of the other half
+                if (tiles < 256) split = (int)((256 + tiles - 1) / tiles);
+                else if (tiles < 512 && tiles % 256 && d.K >= 1024) split = 2;
+            } else if (tiles < 256) {
+                split = (int)((512 + tiles - 1) / tiles);
+            }
             if (split > d.K / 256) split = d.K / 256;
             if (split > 16) split = 16;
+            if (split < 1) split = 1;
             while (split > 1 && (int64_t)split * d.M * d.N > d.workspace_floats) --split;
         }
     }
@@ -628,6 +893,8 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         ST_CHECK_LAUNCH();
         return ST_OK;
     }
+    if (cfg == 12) return launch_dma<2, 1, 4>(d, s);
+    if (cfg == 13) return launch_dma<1, 1, 4>(d, s);
     switch (cfg) {
         case 1: return launch_cfg<2, 2, 2, 2>(d, aligned, s);
         case 2: return launch_cfg<2, 2, 2, 1>(d, aligned, s);
