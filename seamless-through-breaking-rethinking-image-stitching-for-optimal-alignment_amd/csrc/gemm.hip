@@ -391,7 +391,10 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
 //   - DMA source addresses are loop-invariant VGPR offsets + an SGPR offset advanced on the SALU; the only VALU
 //     left is the padding test, redone when the (ky, kx) tap changes (every Cin/32 tiles), never for 1x1;
 //   - waits, barrier, loop control are scalar.
-template <int TM, int TN, int STAGES>
+// PERSIST (plain matrices, K % (32*STAGES) == 0, no split-K): a workgroup walks M tiles g, g+G, g+2G, ... of its
+// column tile with ONE continuous DMA ring, so the operand tiles of the next M tile stream in under the epilogue
+// of the current one (short-K GEMMs -- K = 128 has four K steps per tile -- are otherwise all load latency).
+template <int TM, int TN, int STAGES, bool PERSIST>
 __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d) {
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, ROWS = BM + BN;
     constexpr int PA = BM / 32, PB = BN / 32;      // 1-KiB pieces (8 rows x 128 B) per wave and K step
@@ -410,13 +413,15 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     float* __restrict__ C = d.c + (size_t)bz * d.batch_stride_c;
 
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-    const int nwg = ntm * ntn;
+    const int nwg = PERSIST ? (int)gridDim.x : ntm * ntn;
     int bid = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid % ntn, tile_m = bid / ntn;
+    const int tile_n = bid % ntn, tile_m = bid / ntn;        // PERSIST: tile_m = first M tile, stride G
+    const int G = PERSIST ? nwg / ntn : 1;
+    const int nmt = PERSIST ? (ntm - tile_m + G - 1) / G : 1;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const i32x4 rsrcA = make_rsrc(X, d.a_bytes), rsrcW = make_rsrc(Wt, d.w_bytes);
@@ -447,10 +452,11 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     const int nkt_all = d.K / 32;
     const int per = (nkt_all + split - 1) / split;
     const int kt0 = kz * per;
-    const int ntiles = min(nkt_all, kt0 + per) - kt0;
+    const int nkt = min(nkt_all, kt0 + per) - kt0;          // K steps per output tile
+    const int ntiles = PERSIST ? nmt * nkt : nkt;           // flat (M tile, K step) sequence of this workgroup
 
     // wave-uniform state of the next tile to issue: tap (ky, kx), channel offset c0; byte offsets for the SGPR operand
-    int i_c0, i_ky, i_kx;
+    int i_c0, i_ky, i_kx, i_kt = 0, i_m0 = m0;
     {
         const int k = kt0 * 32, tap = k / d.Cin;
         i_c0 = k - tap * d.Cin; i_ky = tap / d.kw; i_kx = tap - i_ky * d.kw;
@@ -464,19 +470,31 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
             voffA[i] = ok ? (unsigned)(a_base[i] + tapbase) * 4u : ST_OOB;
         }
     };
-    set_tap();
+    auto set_rows = [&]() {                         // PERSIST: A rows of the M tile starting at i_m0 (plain matrix)
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int r = 8 * (wave * PA + i) + (lane >> 3);
+            voffA[i] = (unsigned)(min(i_m0 + r, d.M - 1) * d.ldx + (((lane & 7) ^ ((r >> 1) & 7)) << 2)) * 4u;
+        }
+    };
+    if (PERSIST) set_rows(); else set_tap();
     auto issue_a = [&](int stage, int i) {
         lds_dma16(rsrcA, lds0 + (unsigned)(stage * STAGE_FLOATS + (wave * PA + i) * 256) * 4u, voffA[i], soffA);
     };
     auto issue_b = [&](int stage, int i) {
         lds_dma16(rsrcW, lds0 + (unsigned)(stage * STAGE_FLOATS + BM * 32 + (wave * PB + i) * 256) * 4u, voffB[i], soffB);
     };
-    auto advance = [&]() {                          // scalar, except the padding test when the tap changes
-        soffB += 128u; soffA += 128u; i_c0 += 32;
-        if (i_c0 >= d.Cin) {
-            i_c0 = 0; soffA = 0;
-            if (++i_kx == d.kw) { i_kx = 0; ++i_ky; }
-            set_tap();
+    auto advance = [&]() {                          // scalar, except the address refresh at a tap / M-tile change
+        soffB += 128u; soffA += 128u;
+        if (PERSIST) {
+            if (++i_kt == nkt) { i_kt = 0; soffA = 0; soffB = 0; i_m0 += G * BM; set_rows(); }
+        } else {
+            i_c0 += 32;
+            if (i_c0 >= d.Cin) {
+                i_c0 = 0; soffA = 0;
+                if (++i_kx == d.kw) { i_kx = 0; ++i_ky; }
+                set_tap();
+            }
         }
     };
     // wait until at most `tiles` whole tiles of this wave's DMA pieces are still in flight (wave-uniform)
@@ -565,20 +583,41 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
             mfma_k(1, 0); ST_GAP(read_frags(0, nstage, 0));
             mfma_k(1, 1); mfma_k(1, 2); mfma_k(1, 3);
         };
-        int tb = 0;
-        for (; tb + 2 * STAGES - 1 <= ntiles; tb += STAGES) {           // every tile of the block still feeds a new one
+        if (PERSIST) {
+            for (int mt = 0; mt < nmt; ++mt) {
+                for (int tb = mt * nkt; tb < (mt + 1) * nkt; tb += STAGES) {    // nkt % STAGES == 0: stage == s
+                    if (tb + 2 * STAGES - 1 <= ntiles) {
 #pragma unroll
-            for (int s = 0; s < STAGES; ++s) tile_body(st_true{}, s, tb + s);
-        }
-        for (; tb < ntiles; tb += STAGES) {
+                        for (int s = 0; s < STAGES; ++s) tile_body(st_true{}, s, tb + s);
+                    } else {
 #pragma unroll
-            for (int s = 0; s < STAGES; ++s)
-                if (tb + s < ntiles) tile_body(st_false{}, s, tb + s);
+                        for (int s = 0; s < STAGES; ++s) tile_body(st_false{}, s, tb + s);
+                    }
+                }
+                gemm_tile_epilogue<TM, TN>(d, C, acc, (tile_m + mt * G) * BM, n0, wm, wn, li, lh, 1, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+        } else {
+            int tb = 0;
+            for (; tb + 2 * STAGES - 1 <= ntiles; tb += STAGES) {       // every tile of the block still feeds a new one
+#pragma unroll
+                for (int s = 0; s < STAGES; ++s) tile_body(st_true{}, s, tb + s);
+            }
+            for (; tb < ntiles; tb += STAGES) {
+#pragma unroll
+                for (int s = 0; s < STAGES; ++s)
+                    if (tb + s < ntiles) tile_body(st_false{}, s, tb + s);
+            }
         }
     }
 #undef ST_GAP
 
-    gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
+    if (!PERSIST) gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -802,9 +841,24 @@ template <int TM, int TN, int STAGES>
 static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-    dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : (d.batch > 0 ? d.batch : 1));
+    const int batch = d.batch > 0 ? d.batch : 1;
     const size_t lds = (size_t)STAGES * (BM + BN) * 32 * sizeof(float);
-    auto k = conv_gemm_dma_kernel<TM, TN, STAGES>;
+    // persistent walk over M tiles: plain matrices whose K is a whole number of ring turns and whose grid would
+    // otherwise be many short workgroups (two resident per CU with this LDS footprint)
+    const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M &&
+                       d.Ho * d.Wo == d.M;
+    const int slots = 512 / batch;
+    if (plain && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
+        int G = slots / ntn;
+        if (G > ntm) G = ntm;
+        auto k = conv_gemm_dma_kernel<TM, TN, STAGES, true>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(G * ntn, 1, batch), dim3(256), lds, s, d);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
+    dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : batch);
+    auto k = conv_gemm_dma_kernel<TM, TN, STAGES, false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, d);
     if (d.split_k > 1)
@@ -847,8 +901,10 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     if (cfg == 0) {
         // measured on MI355X (tools/tile_sweep.py, tools/dma_sweep.py): the 64x64 tile wins for every short-K /
         // mid-size shape of this path (more resident workgroups); 128-wide tiles stay selectable through tile_cfg.
+        const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M;
+        const bool stream128 = d.K == 128 && plain && nwg(64, 64) > 512;      // persistent walk hides the 4-step K loop
         if (d.N <= 32) cfg = 4;
-        else cfg = (dma_ok && d.K >= 256 && d.precision == 0) ? 13 : 3;
+        else cfg = (dma_ok && (d.K >= 256 || stream128) && d.precision == 0) ? 13 : 3;
     }
     if (cfg > 10 && !dma_ok) return ST_EINVAL;
     // split-K: a launch that cannot fill the 256 CUs (M = 4096-pixel maps x 64..256 channels) is cut

@@ -45,3 +45,13 @@ for label, B, H, W, Cin, kh, kw, N in SHAPES:
         err = (out - ref).abs().max().item()
         line += f" d{tile}/s{split} {t:6.1f}us err {err:.1e}|"
     print(line, flush=True)
+
+# persistent-M path: ragged M, bias + residual epilogue, column-slice operands
+for M, N, K in ((65000, 128, 128), (40001, 384, 256), (70000, 128, 512)):
+    xw = torch.randn(M, K + 64, device="cuda"); x = xw[:, 32:32 + K]
+    w = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda"); res = torch.randn(M, N, device="cuda")
+    ref = torch.empty(M, N, device="cuda"); out = torch.empty(M, N + 32, device="cuda")[:, :N]
+    ops.conv_gemm(x, w, ref, bias=b, act="gelu", epi="add", aux1=res, tile=3)
+    ops.conv_gemm(x, w, out, bias=b, act="gelu", epi="add", aux1=res, tile=13)
+    torch.cuda.synchronize()
+    print(f"persist check M={M} N={N} K={K}: max err {(out - ref).abs().max().item():.2e}")
