@@ -394,9 +394,10 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
 // PERSIST (plain matrices, K % (32*STAGES) == 0, no split-K): a workgroup walks M tiles g, g+G, g+2G, ... of its
 // column tile with ONE continuous DMA ring, so the operand tiles of the next M tile stream in under the epilogue
 // of the current one (short-K GEMMs -- K = 128 has four K steps per tile -- are otherwise all load latency).
-template <int TM, int TN, int STAGES, bool PERSIST>
+template <int WM, int WN, int TM, int TN, int STAGES, bool PERSIST>
 __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d) {
-    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, ROWS = BM + BN;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, ROWS = BM + BN;
     constexpr int PA = BM / 32, PB = BN / 32;      // 1-KiB pieces (8 rows x 128 B) per wave and K step
     constexpr int PPW = PA + PB;
     constexpr int STAGE_FLOATS = ROWS * 32;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int split = d.split_k > 1 ? d.split_k : 1;
     const int bz = split > 1 ? 0 : blockIdx.z;
     const int kz = split > 1 ? blockIdx.z : 0;
@@ -837,9 +838,9 @@ static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
     return ST_OK;
 }
 
-template <int TM, int TN, int STAGES>
+template <int WM, int WN, int TM, int TN, int STAGES>
 static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
-    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
     const int batch = d.batch > 0 ? d.batch : 1;
     const size_t lds = (size_t)STAGES * (BM + BN) * 32 * sizeof(float);
@@ -851,14 +852,14 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
     if (plain && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
         int G = slots / ntn;
         if (G > ntm) G = ntm;
-        auto k = conv_gemm_dma_kernel<TM, TN, STAGES, true>;
+        auto k = conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(G * ntn, 1, batch), dim3(256), lds, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;
     }
     dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : batch);
-    auto k = conv_gemm_dma_kernel<TM, TN, STAGES, false>;
+    auto k = conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, d);
     if (d.split_k > 1)
@@ -902,9 +903,10 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         // measured on MI355X (tools/tile_sweep.py, tools/dma_sweep.py): the 64x64 tile wins for every short-K /
         // mid-size shape of this path (more resident workgroups); 128-wide tiles stay selectable through tile_cfg.
         const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M;
-        const bool stream128 = d.K == 128 && plain && nwg(64, 64) > 512;      // persistent walk hides the 4-step K loop
-        if (d.N <= 32) cfg = 4;
-        else cfg = (dma_ok && (d.K >= 256 || stream128) && d.precision == 0) ? 13 : 3;
+        const bool stream128 = d.K == 128 && plain && d.N > 32 && nwg(64, 64) > 512;      // persistent walk hides the 4-step K loop
+        const bool dma = dma_ok && (d.K >= 256 || stream128) && d.precision == 0;
+        if (d.N <= 32) cfg = dma ? 14 : 4;
+        else cfg = dma ? 13 : 3;
     }
     if (cfg > 10 && !dma_ok) return ST_EINVAL;
     // split-K: a launch that cannot fill the 256 CUs (M = 4096-pixel maps x 64..256 channels) is cut
@@ -949,8 +951,9 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         ST_CHECK_LAUNCH();
         return ST_OK;
     }
-    if (cfg == 12) return launch_dma<2, 1, 4>(d, s);
-    if (cfg == 13) return launch_dma<1, 1, 4>(d, s);
+    if (cfg == 12) return launch_dma<2, 2, 2, 1, 4>(d, s);
+    if (cfg == 13) return launch_dma<2, 2, 1, 1, 4>(d, s);
+    if (cfg == 14) return launch_dma<4, 1, 1, 1, 4>(d, s);
     switch (cfg) {
         case 1: return launch_cfg<2, 2, 2, 2>(d, aligned, s);
         case 2: return launch_cfg<2, 2, 2, 1>(d, aligned, s);
