@@ -116,6 +116,7 @@ class FlowFormer(ParamTree):
                 gfc2=lin(gb + "mlp.fc2"), gsrn=lin(gb + "attn.norm"),
                 gskx=pack_conv(sk_w[:, :128].contiguous()), gskc=pack_conv(sk_w[:, 128:].contiguous()),
                 gskb=p[gb + "attn.sr_key.bias"].contiguous(), gsv=conv(gb + "attn.sr_value")))
+            vert[-1]["gskv"] = torch.cat([vert[-1]["gskx"], vert[-1]["gsv"][0]], 0).contiguous()   # sr_key (x part) | sr_value
         pk["vert"] = vert
         m = "memory_decoder."
         Q = HP["query_latent_dim"]
@@ -327,8 +328,10 @@ class FlowFormer(ParamTree):
         ops.conv_gemm(ctx, V["gctx"][0], z[:, C:], bias=V["gctx"][1])
         Hk, Wk = H1 // 4, W1 // 4
         Nk = Hk * Wk
-        Tsk = _new(B * Nk, C, dev)                                           # sr_key over the context channels + bias
-        ops.conv_gemm(z[:, C:], V["gskc"], Tsk, geom=(B, H1, W1, 4, 4, 4, 4, 0, 0), bias=V["gskb"])
+        # pre-activation table of the fused [sr_key | sr_value] conv: key half = sr_key over the context channels + bias,
+        # value half = sr_value's bias
+        Tkv = V["gsv"][1].repeat(2).expand(B * Nk, 2 * C).contiguous()
+        ops.conv_gemm(z[:, C:], V["gskc"], Tkv[:, :C], geom=(B, H1, W1, 4, 4, 4, 4, 0, 0), bias=V["gskb"])
         ops.sine_pe(z, Cq, Wg=W1, period=N, accumulate=True)                 # full-grid code on q (twins.py:358-361)
         ops.conv_gemm(z, V["gq"][0], Tq, bias=V["gq"][1])
         ops.conv_gemm(y, V["gq"][0][:, :C], q, aux0=Tq, row_div=nl)
@@ -340,25 +343,23 @@ class FlowFormer(ParamTree):
             ops.conv_gemm(pe_k, V["gk"][0], tk, bias=V["gk"][1])
             self._const[key] = tk
         Tkpe = self._const[key]
-        xk, xv = _new(B * nl * Nk, C, dev), _new(B * nl * Nk, C, dev)          # [b][l][Nk][C]
-        for b in range(B):
-            yb = y[b * N * nl:(b + 1) * N * nl]
-            for name, dst, extra in (("gskx", xk, dict(aux0=Tsk[b * Nk:(b + 1) * Nk], row_mod=Nk)),
-                                     ("gsv", xv, dict(bias=V["gsv"][1]))):
-                wgt = V[name] if name == "gskx" else V[name][0]
-                ops.conv_gemm(yb.view(N, nl * C)[:, :C], wgt, dst[b * nl * Nk:(b + 1) * nl * Nk][:Nk],
-                              geom=(1, H1, W1, 4, 4, 4, 4, 0, 0), batch=nl, bsa=C, bsw=0, bsc=Nk * C, **extra)
-        xkn, xvn = _new(B * nl * Nk, C, dev), _new(B * nl * Nk, C, dev)
-        ops.layernorm(xk, V["gsrn"][0], V["gsrn"][1], xkn, 1e-5)
-        ops.layernorm(xv, V["gsrn"][0], V["gsrn"][1], xvn, 1e-5)
-        kk, vv = _new(B * nl * Nk, C, dev), _new(B * nl * Nk, C, dev)
-        ops.conv_gemm(xkn, V["gk"][0], kk, aux0=Tkpe, row_mod=Nk)
-        ops.conv_gemm(xvn, V["gv"][0], vv, bias=V["gv"][1])
+        # 4x4 stride-4 spatial reduction of every latent's pixel grid (twins.py:364-371): latent l is the channel
+        # slice [l*C, (l+1)*C) of the [B*N, nl*C] row view, so all latents, both batches and both convs are ONE
+        # batched launch; rows come out as [l][b][Nk], columns [key | value]
+        xkv = _new(nl * B * Nk, 2 * C, dev)
+        ops.conv_gemm(y.view(B * N, nl * C)[:, :C], V["gskv"], xkv[:B * Nk], geom=(B, H1, W1, 4, 4, 4, 4, 0, 0),
+                      aux0=Tkv, batch=nl, bsa=C, bsw=0, bsc=B * Nk * 2 * C)
+        xkvn = _new(nl * B * Nk, 2 * C, dev)
+        ops.layernorm(xkv[:, :C], V["gsrn"][0], V["gsrn"][1], xkvn[:, :C], 1e-5)
+        ops.layernorm(xkv[:, C:], V["gsrn"][0], V["gsrn"][1], xkvn[:, C:], 1e-5)
+        kv = _new(nl * B * Nk, 2 * C, dev)
+        ops.conv_gemm(xkvn[:, :C], V["gk"][0], kv[:, :C], aux0=Tkpe, row_mod=Nk)
+        ops.conv_gemm(xkvn[:, C:], V["gv"][0], kv[:, C:], bias=V["gv"][1])
         for b in range(B):
             sl = slice(b * N * nl, (b + 1) * N * nl)
-            s2 = slice(b * nl * Nk, (b + 1) * nl * Nk)
-            ops.attention_kvlds(q[sl], (C, nl * C), kk[s2], (Nk * C, C), vv[s2], (Nk * C, C), att[sl], (C, nl * C), nl, 8, N, Nk,
-                                16, 16 ** -0.5)
+            kb = kv[b * Nk:]
+            ops.attention_kvlds(q[sl], (C, nl * C), kb[:, :C], (B * Nk * 2 * C, 2 * C), kb[:, C:], (B * Nk * 2 * C, 2 * C),
+                                att[sl], (C, nl * C), nl, 8, N, Nk, 16, 16 ** -0.5)
         x3 = _new(R, C, dev)
         ops.conv_gemm(att, V["gproj"][0], x3, bias=V["gproj"][1], aux0=x2)
         return self._mlp(x3, V["gn2"], V["gfc1"], V["gfc2"], 1e-5)
