@@ -817,6 +817,48 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const st_gemm_desc d) 
     }
 }
 
+// Very narrow outputs (N <= 4: the flow head's 2-channel 3x3 conv, gru.py:5-13): an MFMA tile would be > 90 % padding.
+// One wave per output pixel; lanes stride the channels of each tap with float4 loads, N running dot products,
+// one wave reduction at the end.  Pure L2 bandwidth (every input row is re-read kh*kw times).
+template <int NMAX>
+__global__ __launch_bounds__(256) void narrow_conv_kernel(const st_gemm_desc d) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= d.M) return;
+    const int hw = d.Ho * d.Wo;
+    const int b = m / hw, rr = m - b * hw;
+    const int oy = rr / d.Wo, ox = rr - oy * d.Wo;
+    float acc[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+    for (int ky = 0; ky < d.kh; ++ky) {
+        const int iy = oy * d.sh - d.ph + ky;
+        if (iy < 0 || iy >= d.H) continue;
+        for (int kx = 0; kx < d.kw; ++kx) {
+            const int ix = ox * d.sw - d.pw + kx;
+            if (ix < 0 || ix >= d.W) continue;
+            const float* xr = d.a + ((size_t)(b * d.H + iy) * d.W + ix) * d.ldx;
+            const float* wr = d.w + (size_t)(ky * d.kw + kx) * d.Cin;
+            for (int c = lane * 4; c < d.Cin; c += 256) {
+                const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) {
+                    if (n < d.N) {
+                        const float4 wv = *reinterpret_cast<const float4*>(wr + (size_t)n * d.ldw + c);
+                        acc[n] = fmaf(xv.x, wv.x, acc[n]); acc[n] = fmaf(xv.y, wv.y, acc[n]);
+                        acc[n] = fmaf(xv.z, wv.z, acc[n]); acc[n] = fmaf(xv.w, wv.w, acc[n]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n] = wave_sum(acc[n]);
+    if (lane == 0) {
+        const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
+        for (int n = 0; n < d.N && n < NMAX; ++n) d.c[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, acc[n], sc);
+    }
+}
+
 template <int WARPS_M, int WARPS_N, int TM, int TN>
 static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
     constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
@@ -890,6 +932,11 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     const int batch = d.batch > 0 ? d.batch : 1;
     if (d.M <= 8 && d.kh == 1 && d.kw == 1 && aligned && batch == 1 && d.epi == ST_EPI_STORE && !d.aux0 && d.H * d.W == d.M) {
         hipLaunchKernelGGL(skinny_gemm_kernel<8>, dim3((d.N * 64 + 255) / 256), dim3(256), 0, s, d);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
+    if (d.N <= 4 && aligned && batch == 1 && d.epi != ST_EPI_ZR && d.M >= 1024 && d.tile_cfg == 0 && d.split_k <= 1) {
+        hipLaunchKernelGGL(narrow_conv_kernel<4>, dim3((d.M + 3) / 4), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;
     }

@@ -569,3 +569,52 @@ def test_patch_embed_operator_ragged(ops):
     s3, s4, out = torch.empty(M * P, 64, device="cuda"), torch.empty(M * P, 128, device="cuda"), torch.empty(M * P, 128, device="cuda")
     ops.patch_embed(dev(cm.reshape(M, H * W)), w11, 128, pe_bias, s1, s2, s3, s4, out, M, H, W)
     assert (out.cpu().double().view(M, P, 128) - ref).abs().max() < 1e-4
+
+
+# ---------------------------------------------------------------- LDS-DMA pipelined GEMM kernels (tile 12 / 13 / 14)
+@pytest.mark.parametrize("tile,Co", [(12, 130), (13, 130), (14, 24)])
+@pytest.mark.parametrize("geo", [dict(kh=3, kw=3, p=(1, 1), C=64, split=0), dict(kh=1, kw=5, p=(0, 2), C=384, split=3),
+                                 dict(kh=4, kw=4, p=(0, 0), C=32, split=1, s=4), dict(kh=6, kw=3, p=(2, 1), C=32, split=0, s=(2, 1))])
+def test_gemm_dma_pipelined_conv(ops, tile, Co, geo):
+    """global -> LDS DMA ring, swizzled LDS image, zero-fill of padded taps, ragged M / N, split-K slabs."""
+    B, H, W, C, kh, kw = 2, 20, 24, geo["C"], geo["kh"], geo["kw"]
+    st = geo.get("s", 1)
+    st = st if isinstance(st, tuple) else (st, st)
+    x = torch.randn(B, C, H, W, generator=g(10))
+    w = torch.randn(Co, C, kh, kw, generator=g(11)) / (C * kh * kw) ** 0.5
+    b = torch.randn(Co, generator=g(12))
+    conv = F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=geo["p"])
+    Ho, Wo = conv.shape[2:]
+    res = torch.randn(B * Ho * Wo, Co, generator=g(13))
+    ref = F.relu(conv).permute(0, 2, 3, 1).reshape(-1, Co) + res.double()
+    out = torch.empty(B * Ho * Wo, Co + 5, device="cuda")[:, :Co]
+    ops.conv_gemm(nhwc(x), pack_conv_w(w), out, geom=(B, H, W, kh, kw, st[0], st[1], geo["p"][0], geo["p"][1]), bias=dev(b),
+                  act="relu", epi="add", aux1=dev(res), tile=tile, split_k=geo["split"])
+    assert (out.cpu().double() - ref).abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(70001, 130, 256), (65536, 128, 128), (33000, 24, 512)])
+def test_gemm_dma_persistent_walk(ops, M, N, K):
+    """plain matrices with many M tiles: one workgroup walks tiles g, g+G, ... with a continuous DMA ring."""
+    xw = torch.randn(M, K + 32, generator=g(1))
+    w, b = torch.randn(N, K, generator=g(2)) / K ** 0.5, torch.randn(N, generator=g(3))
+    res = torch.randn(M, N, generator=g(4))
+    ref = F.gelu(F.linear(xw[:, 16:16 + K].double(), w.double(), b.double())) + res.double()
+    out = torch.empty(M, N, device="cuda")
+    ops.conv_gemm(dev(xw)[:, 16:16 + K], dev(w), out, bias=dev(b), act="gelu", epi="add", aux1=dev(res))
+    assert (out.cpu().double() - ref).abs().max() < 3e-5
+    out2 = torch.empty(M, N, device="cuda")
+    ops.conv_gemm(dev(xw)[:, 16:16 + K], dev(w), out2, bias=dev(b), act="gelu", epi="add", aux1=dev(res), tile=3)
+    assert torch.equal(out, out2)            # same k order as the register-staged kernel: bit-identical
+
+
+def test_narrow_conv(ops):
+    """N <= 4 (flow head conv2, gru.py:5-13): one wave per output pixel, coords += delta epilogue."""
+    B, H, W, C = 2, 32, 32, 256
+    x = torch.randn(B, C, H, W, generator=g(1))
+    w, b = torch.randn(2, C, 3, 3, generator=g(2)) / (9 * C) ** 0.5, torch.randn(2, generator=g(3))
+    coords = torch.randn(B * H * W, 2, generator=g(4))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, 2) + coords.double()
+    c = dev(coords)
+    ops.conv_gemm(nhwc(x), pack_conv_w(w), c, geom=(B, H, W, 3, 3, 1, 1, 1, 1), bias=dev(b), epi="add", aux1=c)
+    assert (c.cpu().double() - ref).abs().max() < 2e-5
