@@ -72,99 +72,166 @@ __device__ __forceinline__ void gemm_store(const st_gemm_desc& d, float* __restr
     C[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, acc, sc);
 }
 
-// Epilogue shared by the fp32 and the split-bf16 kernels.
+// Epilogue shared by the fp32 and the split-bf16 kernels, in two halves so that the operand loads (bias, the
+// pre-activation addend, residual / gate operands) can be issued BEFORE the K loop and land under its MFMAs:
+// issued after it, they are two or three dependent L2 round trips that a short-K tile (K = 128: 64 MFMAs) cannot hide.
+// acc[r] is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li] of the 32x32 tile.
+// Everything goes through raw buffer instructions: the per-lane offset (first row of the lane, its column) is
+// computed once per 32x32 sub-tile, the 16 row steps are SGPR offsets, and the hardware range check (which
+// includes the SGPR offset on gfx950 -- probed) drops rows >= M; absent operands get a zero-record descriptor, so the
+// loads are unconditional, return 0 and touch no memory.  Result: no per-element address arithmetic or predication
+// on the VALU, which v_mfma_f32_32x32x2_f32 shares its datapath with.
 template <int TM, int TN>
-__device__ __forceinline__ void gemm_tile_epilogue(const st_gemm_desc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN], int m0, int n0,
-                                                   int wm, int wn, int li, int lh, int split, int kz) {
-    // epilogue: acc[r] is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li] of the 32x32 tile.  All mode switches are
-    // wave-uniform and sit OUTSIDE the 16-register loops, and the operand loads of a 16-row column are issued
-    // back to back from clamped rows (a per-element switch serialised 16 dependent L2 round trips: ~9 us per launch).
-    const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
+struct EpiOperands {
+    float sc;
+    float bv[TN];
+    float a0[TM][TN][16];      // aux0 (pre-activation addend)
+    float x1[TM][TN][16];      // aux1
+    float x2[TM][TN][16];      // aux2 (GRU state)
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const float* p, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, (int)soff, 0);
+}
+// row r of a lane's 16 accumulator registers, relative to the lane's first row
+#define ST_EPI_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOperands<TM, TN>& e, int m0, int n0, int wm, int wn,
+                                                   int li, int lh, int split) {
+    const bool raw = split > 1;                                // raw partial sums: nothing to fetch
+    e.sc = (d.scale_ptr && !raw) ? *d.scale_ptr : 1.0f;
     const int half = d.N >> 1;
+    const bool zr = d.epi == ST_EPI_ZR;
+    const long long M = d.M;
+    const __amdgpu_buffer_rsrc_t rb = epi_rsrc(raw ? nullptr : d.bias, (long long)d.N * 4);
+    const bool mapped = d.aux0_row_div > 1 || d.aux0_row_mod > 0;
+    const __amdgpu_buffer_rsrc_t r0 = epi_rsrc(raw ? nullptr : d.aux0, mapped ? 0x7fffffffLL : ((M - 1) * d.ld_aux0 + d.N) * 4);
+    const __amdgpu_buffer_rsrc_t r1 = epi_rsrc((raw || d.epi == ST_EPI_STORE) ? nullptr : d.aux1, ((M - 1) * d.ld_aux1 + (zr ? half : d.N)) * 4);
+    const __amdgpu_buffer_rsrc_t r2 = epi_rsrc((raw || d.epi != ST_EPI_GRU) ? nullptr : d.aux2, ((M - 1) * d.ld_aux2 + d.N) * 4);
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * TN * 32 + jn * 32 + li;
+        const int nc = n < d.N ? n : d.N - 1;
+        e.bv[jn] = buf_ld(rb, (unsigned)nc * 4u, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row0 = m0 + wm * TM * 32 + i * 32 + 4 * lh;              // this lane's first row
+            // aux0: identity rows, or the (row / div) % mod table mapping (per element; small tables).  Operands the
+            // mode does not use are not fetched (wave-uniform branches; their registers stay undefined and unread).
+            if (!raw && d.aux0) {
+                if (mapped) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int ar = min(row0 + ST_EPI_ROW(r), d.M - 1);
+                        if (d.aux0_row_div > 1) ar = ar / d.aux0_row_div;
+                        if (d.aux0_row_mod > 0) ar = ar % d.aux0_row_mod;
+                        e.a0[i][jn][r] = buf_ld(r0, (unsigned)(ar * d.ld_aux0 + nc) * 4u, 0);
+                    }
+                } else {
+                    const unsigned v0 = (unsigned)(row0 * d.ld_aux0 + nc) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e.a0[i][jn][r] = buf_ld(r0, v0, (unsigned)(ST_EPI_ROW(r) * d.ld_aux0) * 4u);
+                }
+            }
+            if (!raw && d.epi != ST_EPI_STORE) {
+                const int c1 = zr ? (nc >= half ? nc - half : 0) : nc;
+                const unsigned v1 = (unsigned)(row0 * d.ld_aux1 + c1) * 4u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e.x1[i][jn][r] = buf_ld(r1, v1, (unsigned)(ST_EPI_ROW(r) * d.ld_aux1) * 4u);
+                if (d.epi == ST_EPI_GRU) {
+                    const unsigned v2 = (unsigned)(row0 * d.ld_aux2 + nc) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e.x2[i][jn][r] = buf_ld(r2, v2, (unsigned)(ST_EPI_ROW(r) * d.ld_aux2) * 4u);
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN],
+                                                    const EpiOperands<TM, TN>& e, int m0, int n0, int wm, int wn, int li, int lh,
+                                                    int split, int kz) {
+    const int half = d.N >> 1;
+    const long long M = d.M;
+    if (split > 1) {                                           // raw partial sums -> slab kz of the workspace
+        const __amdgpu_buffer_rsrc_t rw = epi_rsrc(d.workspace + (size_t)kz * d.M * d.N, M * d.N * 4);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int n = n0 + wn * TN * 32 + jn * 32 + li;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row0 = m0 + wm * TM * 32 + i * 32 + 4 * lh;
+                const unsigned vo = n < d.N ? (unsigned)(row0 * d.N + n) * 4u : ST_OOB;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) buf_st(acc[i][jn][r], rw, vo, (unsigned)(ST_EPI_ROW(r) * d.N) * 4u);
+            }
+        }
+        return;
+    }
+    const bool zr = d.epi == ST_EPI_ZR;
+    const __amdgpu_buffer_rsrc_t rc = epi_rsrc(C, ((M - 1) * d.ldc + (zr ? half : d.N)) * 4);
+    const __amdgpu_buffer_rsrc_t rc2 = epi_rsrc(zr ? d.c2 : nullptr, ((M - 1) * d.ldc2 + half) * 4);
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int n = n0 + wn * TN * 32 + jn * 32 + li;
         const bool ncol = n < d.N;
-        const int nc = ncol ? n : d.N - 1;
-        const float bv = d.bias ? d.bias[nc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * lh;
-            int mr[16];
-            bool ok[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                ok[r] = ncol && m < d.M;
-                mr[r] = m < d.M ? m : d.M - 1;
-            }
-            if (split > 1) {                                   // raw partial sums -> slab
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (ok[r]) d.workspace[((size_t)kz * d.M + mr[r]) * d.N + n] = acc[i][jn][r];
-                continue;
-            }
+            const int row0 = m0 + wm * TM * 32 + i * 32 + 4 * lh;
             float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[i][jn][r] * d.alpha + bv;
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][jn][r] * d.alpha + e.bv[jn];
             if (d.aux0) {
-                float a0[16];
-                if (d.aux0_row_div > 1 || d.aux0_row_mod > 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int ar = mr[r];
-                        if (d.aux0_row_div > 1) ar = ar / d.aux0_row_div;
-                        if (d.aux0_row_mod > 0) ar = ar % d.aux0_row_mod;
-                        a0[r] = d.aux0[(size_t)ar * d.ld_aux0 + nc];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a0[r] = d.aux0[(size_t)mr[r] * d.ld_aux0 + nc];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += a0[r];
+                for (int r = 0; r < 16; ++r) v[r] += e.a0[i][jn][r];
             }
             if (d.act != ST_ACT_NONE) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = st_act(v[r], d.act);
             }
-            if (d.epi == ST_EPI_STORE) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = v[r];
-            } else if (d.epi == ST_EPI_ZR) {
-                if (nc < half) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = v[r];
-                } else {
-                    float h[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) h[r] = d.aux1[(size_t)mr[r] * d.ld_aux1 + (nc - half)];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (ok[r]) d.c2[(size_t)mr[r] * d.ldc2 + (n - half)] = v[r] * h[r];
-                }
-            } else {
-                float x1[16], x2[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x1[r] = d.aux1[(size_t)mr[r] * d.ld_aux1 + nc];
-                if (d.epi == ST_EPI_GRU) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) x2[r] = d.aux2[(size_t)mr[r] * d.ld_aux2 + nc];
-                }
+            if (zr) {
+                const unsigned vc = (ncol && n < half) ? (unsigned)(row0 * d.ldc + n) * 4u : ST_OOB;
+                const unsigned vc2 = (ncol && n >= half) ? (unsigned)(row0 * d.ldc2 + n - half) * 4u : ST_OOB;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float o = v[r];
-                    if (d.epi == ST_EPI_ADD) o = v[r] + x1[r];
-                    else if (d.epi == ST_EPI_MUL) o = v[r] * x1[r];
-                    else if (d.epi == ST_EPI_GRU) o = (1.0f - x1[r]) * x2[r] + x1[r] * v[r];
-                    else if (d.epi == ST_EPI_AXPY) o = x1[r] + sc * v[r];
-                    if (ok[r]) C[(size_t)mr[r] * d.ldc + n] = o;
+                    buf_st(v[r], rc, vc, (unsigned)(ST_EPI_ROW(r) * d.ldc) * 4u);
+                    buf_st(v[r] * e.x1[i][jn][r], rc2, vc2, (unsigned)(ST_EPI_ROW(r) * d.ldc2) * 4u);
+                }
+            } else {
+                const unsigned vc = ncol ? (unsigned)(row0 * d.ldc + n) * 4u : ST_OOB;
+                if (d.epi == ST_EPI_STORE) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) buf_st(v[r], rc, vc, (unsigned)(ST_EPI_ROW(r) * d.ldc) * 4u);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float x1 = e.x1[i][jn][r];
+                        float o = v[r] + x1;                                   // ST_EPI_ADD
+                        if (d.epi == ST_EPI_MUL) o = v[r] * x1;
+                        else if (d.epi == ST_EPI_GRU) o = (1.0f - x1) * e.x2[i][jn][r] + x1 * v[r];
+                        else if (d.epi == ST_EPI_AXPY) o = x1 + e.sc * v[r];
+                        buf_st(o, rc, vc, (unsigned)(ST_EPI_ROW(r) * d.ldc) * 4u);
+                    }
                 }
             }
         }
     }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_tile_epilogue(const st_gemm_desc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                                   int wm, int wn, int li, int lh, int split, int kz) {
+    EpiOperands<TM, TN> e;
+    gemm_epilogue_load<TM, TN>(d, e, m0, n0, wm, wn, li, lh, split);
+    gemm_epilogue_store<TM, TN>(d, C, acc, e, m0, n0, wm, wn, li, lh, split, kz);
 }
 
 template <int WARPS_M, int WARPS_N, int TM, int TN, bool VEC>
@@ -545,6 +612,12 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     };
 #define ST_GAP(stmt) do { stmt; __builtin_amdgcn_sched_barrier(0); } while (0)
 
+    // epilogue operands are fetched ahead of the K loop (ordinary loads, older than every DMA of the ring: the
+    // counted vmcnt waits below only ever over-wait because of them)
+    EpiOperands<TM, TN> eop;
+    if (!PERSIST) gemm_epilogue_load<TM, TN>(d, eop, m0, n0, wm, wn, li, lh, split);
+    __builtin_amdgcn_sched_barrier(0);
+
     if (ntiles > 0) {
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
@@ -586,6 +659,8 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
         };
         if (PERSIST) {
             for (int mt = 0; mt < nmt; ++mt) {
+                gemm_epilogue_load<TM, TN>(d, eop, (tile_m + mt * G) * BM, n0, wm, wn, li, lh, 1);   // lands under the MFMAs
+                __builtin_amdgcn_sched_barrier(0);
                 for (int tb = mt * nkt; tb < (mt + 1) * nkt; tb += STAGES) {    // nkt % STAGES == 0: stage == s
                     if (tb + 2 * STAGES - 1 <= ntiles) {
 #pragma unroll
@@ -595,7 +670,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
                         for (int s = 0; s < STAGES; ++s) tile_body(st_false{}, s, tb + s);
                     }
                 }
-                gemm_tile_epilogue<TM, TN>(d, C, acc, (tile_m + mt * G) * BM, n0, wm, wn, li, lh, 1, 0);
+                gemm_epilogue_store<TM, TN>(d, C, acc, eop, (tile_m + mt * G) * BM, n0, wm, wn, li, lh, 1, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -618,7 +693,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     }
 #undef ST_GAP
 
-    if (!PERSIST) gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
+    if (!PERSIST) gemm_epilogue_store<TM, TN>(d, C, acc, eop, m0, n0, wm, wn, li, lh, split, kz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -924,6 +999,14 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         const int64_t a_rows = (int64_t)(d.M / (d.Ho * d.Wo)) * d.H * d.W;
         const int64_t ab = ((a_rows - 1) * d.ldx + d.Cin) * 4, wb = ((int64_t)(d.N - 1) * d.ldw + d.K) * 4;
         if (ab >= (int64_t)ST_OOB || wb >= (int64_t)ST_OOB) return ST_EINVAL;
+        // the epilogue addresses C / aux operands with 32-bit buffer offsets (first row of a lane + SGPR row step)
+        const int64_t lim = (int64_t)1 << 31, rows = (int64_t)d.M + 256;
+        int64_t ldmax = d.ldc > d.N ? d.ldc : d.N;
+        if (d.aux0 && d.ld_aux0 > ldmax) ldmax = d.ld_aux0;
+        if (d.aux1 && d.ld_aux1 > ldmax) ldmax = d.ld_aux1;
+        if (d.aux2 && d.ld_aux2 > ldmax) ldmax = d.ld_aux2;
+        if (d.c2 && d.ldc2 > ldmax) ldmax = d.ldc2;
+        if (rows * ldmax * 4 >= lim) return ST_EINVAL;
         d.a_bytes = (uint32_t)ab; d.w_bytes = (uint32_t)wb;
     }
     const bool aligned = ((uintptr_t)d.a % 16 == 0) && ((uintptr_t)d.w % 16 == 0) && (d.ldx % 4 == 0) &&
