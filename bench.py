@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-corr-roofline", action="store_true", help="skip the stand-alone corr-volume timing (PMC passes)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
     ap.add_argument("--streams", type=int, default=3, help="independent pairs in flight per GPU (one hipGraph + HIP stream each)")
     args = ap.parse_args()
@@ -182,12 +183,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "UDIS-D-shaped 512x512 pairs, batch=1, FlowHomoAdpater.forward(type=test_eval)",
                        "pairs_per_step_per_gpu": 1, "launch": "eager" if args.eager else "hipGraph replay", "pairs_in_flight": nstreams, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA implicit GEMM, all launches of one step)",
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_dma_kernel + conv_gemm_kernel (fp32 MFMA implicit GEMM: all st_conv_gemm launches of one step)",
                          "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied)",
                          "launches_per_step": launches, "gflop_per_step": flops / 1e9,
                          "kernel_ms_per_step": gemm_ms},
-            "corr_volume": corr_roofline(ops),
+            "corr_volume": None if args.no_corr_roofline else corr_roofline(ops),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -1,0 +1,30 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (counter_collection.csv) per kernel and write the
+per-launch HBM traffic of the GEMM kernels to profiles/<tag>_traffic.json (+ per-kernel CSVs).
+Units: the counters are KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md HBM section: wide coalesced reads are tallied at
+half size on gfx950); WRITE_SIZE is exact (calibrated on st_corr_volume B=8: 8 x 64 MiB)."""
+import collections, csv, json, re, sys
+fetch_csv, write_csv, tag, cmd = sys.argv[1:5]
+def per_kernel(path):
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        k = re.sub(r"\(.*", "", r["Kernel_Name"]).strip()
+        a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
+    return agg
+F, W = per_kernel(fetch_csv), per_kernel(write_csv)
+for name, agg in (("FETCH_SIZE", F), ("WRITE_SIZE", W)):
+    with open(f"profiles/{tag}_pmc_{name}_by_kernel.csv", "w") as f:
+        f.write("kernel,dispatches,sum_KiB,avg_KiB\n")
+        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write(f'"{k}",{n},{v:.0f},{v / n:.1f}\n')
+gemm = [k for k in F if "conv_gemm" in k]
+forwards = F.get("patch_conv1_kernel", [1])[0]
+launches = sum(F[k][0] for k in gemm)
+fetch = sum(F[k][1] for k in gemm) * 1024 * 2
+write = sum(W[k][1] for k in gemm if k in W) * 1024
+out = dict(source=cmd, kernel="conv_gemm_dma_kernel + conv_gemm_kernel (all instantiations)", forwards_profiled=forwards,
+           launches_per_step=launches / forwards, fetch_bytes_per_step=fetch / forwards, write_bytes_per_step=write / forwards,
+           hbm_bytes_per_launch=(fetch + write) / launches,
+           corrections="FETCH_SIZE x2 (MI355X_MICROARCH.md HBM section, 16-B/lane loads and buffer_load...lds alike); WRITE_SIZE x1",
+           per_kernel={k: dict(launches=F[k][0], fetch_bytes=F[k][1] * 2048, write_bytes=W.get(k, [0, 0.0])[1] * 1024) for k in gemm})
+json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))
