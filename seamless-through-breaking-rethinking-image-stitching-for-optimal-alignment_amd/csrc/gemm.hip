@@ -449,7 +449,7 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
     return r;
 }
 
-// The K loop is written around one measured fact (tools/mfma_gap: v_mfma_f32_32x32x2_f32 shares the fp32 FMA
+// The K loop is written around one measured fact (tools/probes/mfma_gap.hip: v_mfma_f32_32x32x2_f32 shares the fp32 FMA
 // datapath with the VALU): every VALU instruction issued between two MFMAs costs 4-8 cycles of matrix time
 // (2 VALU per MFMA: 67 -> 89 cycles per MFMA at one wave per SIMD), while SALU (<= 4 per MFMA), ds_read and
 // buffer_load...lds issue for free.  So the loop body contains NO per-tile VALU work:
