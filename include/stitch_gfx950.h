@@ -51,6 +51,7 @@ typedef struct st_gemm_desc {
     uint32_t a_bytes, w_bytes;  /* filled by the library: extents of A / W for the buffer descriptors  */
     int32_t precision;     /* 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain); 1: fp32-grade bf16x6 split
                               (x = x1+x2+x3 exactly in bf16, six partial products, fp32 accumulate)       */
+    int64_t batch_stride_aux1;  /* floats; aux1 of batch z starts at aux1 + z * batch_stride_aux1          */
 } st_gemm_desc;
 
 /* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.

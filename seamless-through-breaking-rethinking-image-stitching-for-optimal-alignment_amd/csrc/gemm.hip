@@ -113,7 +113,8 @@ __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOpe
     const __amdgpu_buffer_rsrc_t rb = epi_rsrc(raw ? nullptr : d.bias, (long long)d.N * 4);
     const bool mapped = d.aux0_row_div > 1 || d.aux0_row_mod > 0;
     const __amdgpu_buffer_rsrc_t r0 = epi_rsrc(raw ? nullptr : d.aux0, mapped ? 0x7fffffffLL : ((M - 1) * d.ld_aux0 + d.N) * 4);
-    const __amdgpu_buffer_rsrc_t r1 = epi_rsrc((raw || d.epi == ST_EPI_STORE) ? nullptr : d.aux1, ((M - 1) * d.ld_aux1 + (zr ? half : d.N)) * 4);
+    const float* aux1 = d.aux1 ? d.aux1 + (size_t)(d.batch > 1 ? blockIdx.z : 0) * d.batch_stride_aux1 : nullptr;
+    const __amdgpu_buffer_rsrc_t r1 = epi_rsrc((raw || d.epi == ST_EPI_STORE) ? nullptr : aux1, ((M - 1) * d.ld_aux1 + (zr ? half : d.N)) * 4);
     const __amdgpu_buffer_rsrc_t r2 = epi_rsrc((raw || d.epi != ST_EPI_GRU) ? nullptr : d.aux2, ((M - 1) * d.ld_aux2 + d.N) * 4);
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {

@@ -120,12 +120,14 @@ int st_gma_aggregate(const float* attn, const float* mf, int32_t ld_mf, const fl
                      float* out, int32_t ld_out, int32_t B, int32_t N, void* workspace, int64_t workspace_floats,
                      void* stream) {
     if (!attn || !mf || !w_v || !gamma || !vT || !out || B <= 0 || N <= 0) return ST_EINVAL;
-    for (int b = 0; b < B; ++b) {
-        const float* mfb = mf + (int64_t)b * N * ld_mf;
-        float* vTb = vT + (int64_t)b * 128 * N;
-        ST_TRY(Gemm(w_v, 128, mfb, ld_mf, vTb, N, 128, N, 128).work(workspace, workspace_floats).run(stream));
-        ST_TRY(Gemm(attn + (int64_t)b * N * N, N, vTb, N, out + (int64_t)b * N * ld_out, ld_out, N, 128, N)
-                   .epi(ST_EPI_AXPY, mfb, ld_mf).scale(gamma).work(workspace, workspace_floats).run(stream));
+    // both products run as batched launches over b (grid.z): vT[b] = Wv . mf[b]^T, then out[b] = mf[b] + gamma attn[b] vT[b]^T
+    ST_TRY(Gemm(w_v, 128, mf, ld_mf, vT, N, 128, N, 128).batched(B, 0, (int64_t)N * ld_mf, (int64_t)128 * N).run(stream));
+    {
+        Gemm g(attn, N, vT, N, out, ld_out, N, 128, N);
+        g.epi(ST_EPI_AXPY, mf, ld_mf).scale(gamma).batched(B, (int64_t)N * N, (int64_t)128 * N, (int64_t)N * ld_out);
+        g.d.batch_stride_aux1 = (int64_t)N * ld_mf;
+        if (B == 1) g.work(workspace, workspace_floats);        // a single map cannot fill the chip without split-K
+        ST_TRY(g.run(stream));
     }
     return ST_OK;
 }

@@ -78,7 +78,7 @@ class workspace_scope:
 
 
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
-              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, M=None, tile=0, split_k=0, out2=None, precision=None):
+              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, M=None, tile=0, split_k=0, out2=None, precision=None):
     """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
 
     x: 2-D view [rows, Cin] of a channels-last activation; geom=(B,H,W,kh,kw,sh,sw,ph,pw) or None (1x1).
@@ -112,6 +112,7 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     d.aux0_row_div, d.aux0_row_mod = row_div, row_mod
     d.act, d.epi, d.alpha = ACT[act], EPI[epi], alpha
     d.batch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_c = batch, bsa, bsw, bsc
+    d.batch_stride_aux1 = bsx1
     d.tile_cfg = tile
     d.precision = GEMM_PRECISION if precision is None else precision
     d.split_k = split_k
