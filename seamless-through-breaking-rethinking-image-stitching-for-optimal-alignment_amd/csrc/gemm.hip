@@ -111,8 +111,13 @@ __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOpe
     const bool zr = d.epi == ST_EPI_ZR;
     const long long M = d.M;
     const __amdgpu_buffer_rsrc_t rb = epi_rsrc(raw ? nullptr : d.bias, (long long)d.N * 4);
-    const bool mapped = d.aux0_row_div > 1 || d.aux0_row_mod > 0;
-    const __amdgpu_buffer_rsrc_t r0 = epi_rsrc(raw ? nullptr : d.aux0, mapped ? 0x7fffffffLL : ((M - 1) * d.ld_aux0 + d.N) * 4);
+    // aux0 row = (m / div) % mod.  div == 8 without mod (one table row per pixel, 8 latent rows each -- the vertical
+    // layers' q / k tables) keeps the SGPR-step form: a lane's rows m0' + (r&3) + 8*(r>>2), m0' % 4 == 0, map to
+    // table rows m0'/8 + (r>>2), i.e. four loads.  Other mappings are computed per element (small GEMMs only).
+    const bool div8 = d.aux0_row_div == 8 && d.aux0_row_mod <= 0;
+    const bool mapped = !div8 && (d.aux0_row_div > 1 || d.aux0_row_mod > 0);
+    const __amdgpu_buffer_rsrc_t r0 = epi_rsrc(raw ? nullptr : d.aux0, mapped ? 0x7fffffffLL
+                                               : div8 ? (((M + 7) / 8 - 1) * d.ld_aux0 + d.N) * 4 : ((M - 1) * d.ld_aux0 + d.N) * 4);
     const float* aux1 = d.aux1 ? d.aux1 + (size_t)(d.batch > 1 ? blockIdx.z : 0) * d.batch_stride_aux1 : nullptr;
     const __amdgpu_buffer_rsrc_t r1 = epi_rsrc((raw || d.epi == ST_EPI_STORE) ? nullptr : aux1, ((M - 1) * d.ld_aux1 + (zr ? half : d.N)) * 4);
     const __amdgpu_buffer_rsrc_t r2 = epi_rsrc((raw || d.epi != ST_EPI_GRU) ? nullptr : d.aux2, ((M - 1) * d.ld_aux2 + d.N) * 4);
@@ -135,6 +140,13 @@ __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOpe
                         if (d.aux0_row_mod > 0) ar = ar % d.aux0_row_mod;
                         e.a0[i][jn][r] = buf_ld(r0, (unsigned)(ar * d.ld_aux0 + nc) * 4u, 0);
                     }
+                } else if (div8) {
+                    const unsigned v0 = (unsigned)((row0 >> 3) * d.ld_aux0 + nc) * 4u;
+                    float t4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t4[q] = buf_ld(r0, v0, (unsigned)(q * d.ld_aux0) * 4u);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e.a0[i][jn][r] = t4[r >> 2];
                 } else {
                     const unsigned v0 = (unsigned)(row0 * d.ld_aux0 + nc) * 4u;
 #pragma unroll

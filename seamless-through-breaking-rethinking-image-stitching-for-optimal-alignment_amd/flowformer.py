@@ -116,6 +116,7 @@ class FlowFormer(ParamTree):
                 gfc2=lin(gb + "mlp.fc2"), gsrn=lin(gb + "attn.norm"),
                 gskx=pack_conv(sk_w[:, :128].contiguous()), gskc=pack_conv(sk_w[:, 128:].contiguous()),
                 gskb=p[gb + "attn.sr_key.bias"].contiguous(), gsv=conv(gb + "attn.sr_value")))
+            vert[-1]["lqkv"] = torch.cat([vert[-1]["lq"][0][:, :128], vert[-1]["lk"][0][:, :128], vert[-1]["lv"][0]], 0).contiguous()
             vert[-1]["gskv"] = torch.cat([vert[-1]["gskx"], vert[-1]["gsv"][0]], 0).contiguous()   # sr_key (x part) | sr_value
         pk["vert"] = vert
         m = "memory_decoder."
@@ -299,13 +300,14 @@ class FlowFormer(ParamTree):
         z = _new(B * N, Cq, dev, zero=True)
         ops.conv_gemm(ctx, V["lctx"][0], z[:, C:], bias=V["lctx"][1])
         ops.sine_pe(z, Cq, Wg=W1, ws=7, period=N, accumulate=True)          # window-local code (twins.py:285-288)
-        Tq, Tk = _new(B * N, C, dev), _new(B * N, C, dev)
-        ops.conv_gemm(z, V["lq"][0], Tq, bias=V["lq"][1])
-        ops.conv_gemm(z, V["lk"][0], Tk, bias=V["lk"][1])
-        q, k, v = _new(R, C, dev), _new(R, C, dev), _new(R, C, dev)
-        ops.conv_gemm(y, V["lq"][0][:, :C], q, aux0=Tq, row_div=nl)
-        ops.conv_gemm(y, V["lk"][0][:, :C], k, aux0=Tk, row_div=nl)
-        ops.conv_gemm(y, V["lv"][0], v, bias=V["lv"][1])
+        # q | k | v of every latent row in ONE N = 384 product: the context / position part of q and k is a per-pixel
+        # table (row = m / nl), v's bias rides in the same table
+        T = V["lv"][1].repeat(3).expand(B * N, 3 * C).contiguous()
+        ops.conv_gemm(z, V["lq"][0], T[:, :C], bias=V["lq"][1])
+        ops.conv_gemm(z, V["lk"][0], T[:, C:2 * C], bias=V["lk"][1])
+        qkv = _new(R, 3 * C, dev)
+        ops.conv_gemm(y, V["lqkv"], qkv, aux0=T, row_div=nl)
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         key = ("lsa_pad", id(V))
         if key not in self._const:
             zp = _new(49, Cq, dev, zero=True)                                 # zero token + window code
@@ -318,7 +320,8 @@ class FlowFormer(ParamTree):
         att = _new(R, C, dev)
         for b in range(B):
             sl = slice(b * N * nl, (b + 1) * N * nl)
-            ops.window_attention(q[sl], k[sl], v[sl], C, nl * C, qp, kp, vp, att[sl], C, nl * C, nl, H1, W1, 8, 16, 7, 16 ** -0.5)
+            ops.window_attention(q[sl], k[sl], v[sl], 3 * C, nl * 3 * C, qp, kp, vp, att[sl], C, nl * C, nl, H1, W1, 8, 16, 7,
+                                 16 ** -0.5)
         x1 = _new(R, C, dev)
         ops.conv_gemm(att, V["lproj"][0], x1, bias=V["lproj"][1], aux0=x)
         x2 = self._mlp(x1, V["ln2"], V["lfc1"], V["lfc2"], 1e-5)
@@ -333,6 +336,7 @@ class FlowFormer(ParamTree):
         Tkv = V["gsv"][1].repeat(2).expand(B * Nk, 2 * C).contiguous()
         ops.conv_gemm(z[:, C:], V["gskc"], Tkv[:, :C], geom=(B, H1, W1, 4, 4, 4, 4, 0, 0), bias=V["gskb"])
         ops.sine_pe(z, Cq, Wg=W1, period=N, accumulate=True)                 # full-grid code on q (twins.py:358-361)
+        Tq, q = _new(B * N, C, dev), _new(R, C, dev)
         ops.conv_gemm(z, V["gq"][0], Tq, bias=V["gq"][1])
         ops.conv_gemm(y, V["gq"][0][:, :C], q, aux0=Tq, row_div=nl)
         key = ("gsa_kpe", id(V), Hk, Wk)
