@@ -669,9 +669,91 @@ __global__ __launch_bounds__(256) void patch_conv1_kernel(const float* __restric
         o[c] = make_float4(fmaxf(acc[4 * c], 0.f), fmaxf(acc[4 * c + 1], 0.f), fmaxf(acc[4 * c + 2], 0.f), fmaxf(acc[4 * c + 3], 0.f));
 }
 
+// The same convolution on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): out[16 px, 16 ch] += A[16 px, 4 taps] .
+// W[4 taps, 16 ch], nine MFMAs for the 36 taps.  One workgroup per cost map: the map is staged once into LDS with a zero
+// halo (pad 2 left/top, >= 3 right/bottom), every lane gathers its A value -- one input pixel per (output pixel, tap) --
+// with a single ds_read_b32 from a running per-tap address; a wave walks output rows, 16 pixels per tile.
+// The scalar kernel above spends ~25 address / predicate instructions per tap-FMA group on the VALU that
+// v_mfma shares; here a tile costs 9 MFMAs + 9 LDS reads + ~12 VALU.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void patch_conv1_mfma_kernel(const float* __restrict__ maps, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                               int W, int Ho, int Wo, int Hl, int Wl) {
+    extern __shared__ __attribute__((aligned(16))) float img[];          // [Hl][Wl], image pixel (y, x) at [y+2][x+2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t m = blockIdx.x;
+    const float* im = maps + m * (size_t)H * W;
+    // stage the map: interior by 16-B loads (W % 4 == 0; 16 threads per row, all of a thread's loads issued before its LDS
+    // writes), halo zeroed separately (disjoint addresses, so one barrier)
+    {
+        const int ty = tid >> 4, tx = (tid & 15) * 4;
+        for (int y0 = 0; y0 < H; y0 += 64) {
+            for (int x0 = 0; x0 < W; x0 += 64) {
+                float4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = y0 + ty + 16 * k, x = x0 + tx;
+                    v[k] = (y < H && x < W) ? *reinterpret_cast<const float4*>(im + (size_t)y * W + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = y0 + ty + 16 * k, x = x0 + tx;
+                    if (y < H && x < W) {
+                        float2* dst = reinterpret_cast<float2*>(img + (y + 2) * Wl + x + 2);       // Wl even: 8-B aligned
+                        dst[0] = make_float2(v[k].x, v[k].y);
+                        dst[1] = make_float2(v[k].z, v[k].w);
+                    }
+                }
+            }
+        }
+        for (int yl = wave; yl < Hl; yl += 4) {
+            const bool full = yl < 2 || yl >= H + 2;
+            for (int xl = lane; xl < Wl; xl += 64)
+                if (full || xl < 2 || xl >= W + 2) img[yl * Wl + xl] = 0.f;
+        }
+    }
+    __syncthreads();
+    const int px = lane & 15, ks = lane >> 4;                              // A: pixel px of the tile, k slot ks; B: channel px
+    float wv[9];
+    int toff[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int t = 4 * j + ks, ky = t / 6, kx = t - ky * 6;
+        wv[j] = w[t * 16 + px];
+        toff[j] = ky * Wl + kx + 2 * px;
+    }
+    const float bv = bias[px];
+    const int ntx = (Wo + 15) >> 4;
+    for (int oy = wave; oy < Ho; oy += 4) {
+        for (int tx = 0; tx < ntx; ++tx) {
+            const int base = 2 * oy * Wl + 32 * tx;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 9; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(img[base + toff[j]], wv[j], acc, 0, 0, 0);
+            // acc[r]: pixel 4*ks + r of the tile, channel px
+            float* o = out + ((m * Ho + oy) * (size_t)Wo + 16 * tx + 4 * ks) * 16 + px;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * tx + 4 * ks + r < Wo) o[r * 16] = fmaxf(acc[r] + bv, 0.f);
+        }
+    }
+}
+
 extern "C" int st_patch_conv1(const float* maps, const float* w36x16, const float* bias, float* out, int32_t M, int32_t H,
                               int32_t W, int32_t Ho, int32_t Wo, void* stream) {
     if (!maps || !w36x16 || !bias || !out || M <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return ST_EINVAL;
+    // LDS image: rows 0 .. 2*Ho+3, columns 0 .. 2*roundup16(Wo)+3 (the last partial tile reads, but never stores)
+    const int Hl = 2 * Ho + 4, Wl = 2 * ((Wo + 15) / 16 * 16) + 4;
+    const size_t lds = (size_t)Hl * Wl * sizeof(float);
+    if (H + 2 <= Hl && W + 2 <= Wl && lds <= 64 * 1024 && W % 4 == 0 && ((uintptr_t)maps % 16) == 0) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)patch_conv1_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(patch_conv1_mfma_kernel, dim3(M), dim3(256), lds, (hipStream_t)stream, maps, w36x16, bias, out, H, W, Ho, Wo,
+                           Hl, Wl);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     const size_t total = (size_t)M * Ho * Wo;
     hipLaunchKernelGGL(patch_conv1_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, maps, w36x16, bias, out,
                        M, H, W, Ho, Wo);
