@@ -52,6 +52,8 @@ typedef struct st_gemm_desc {
     int32_t precision;     /* 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain); 1: fp32-grade bf16x6 split
                               (x = x1+x2+x3 exactly in bf16, six partial products, fp32 accumulate)       */
     int64_t batch_stride_aux1;  /* floats; aux1 of batch z starts at aux1 + z * batch_stride_aux1          */
+    int32_t dh, dw;        /* conv dilation (0 / 1 = dense): tap (ky,kx) reads pixel (oy*sh-ph+ky*dh, ox*sw-pw+kx*dw);
+                              Ho / Wo are the caller's (PyTorch: H + 2*ph - dh*(kh-1) - 1) / sh + 1)            */
 } st_gemm_desc;
 
 /* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.
@@ -159,7 +161,8 @@ int st_mesh_bounds(const float* H, float* out4, int32_t B, float width, float he
 /* warp() = grid_sample(bilinear, zeros, align_corners=True) at pix+flow (core/warp_utils.py:54-80). */
 int st_flow_warp(const float* x, const float* flow, const float* mul, float* out, int32_t B, int32_t C,
                  int32_t H, int32_t W, void* stream);
-/* F.interpolate bilinear: resize_flow (warp_utils.py:38-46) / Resize((512,512)) (flowHomoAdpater.py:14). */
+/* F.interpolate bilinear: resize_flow (warp_utils.py:38-46) / Resize((512,512)) (flowHomoAdpater.py:14);
+ * align_corners == 2: scale_factor form of out.py:281 (half-pixel centres, source step (div0, div1) = 1/scale). */
 int st_resize_bilinear(const float* x, float* out, int32_t planes, int32_t H, int32_t W, int32_t oh, int32_t ow,
                        int32_t align_corners, float div0, float div1, int32_t ndiv, void* stream);
 /* compute_range_map (core/warp_utils.py:114-175), deterministic fixed-point splat.                  */
@@ -222,6 +225,20 @@ int st_gma_aggregate(const float* attn, const float* mf, int32_t ld_mf, const fl
 int st_sepconv_gru(float* hxA, float* hxB, int32_t ld, float* zbuf, const float* tab1, const float* tab2,
                    int32_t ld_tab, const float* w_zr1, const float* w_q1, const float* w_zr2, const float* w_q2,
                    int32_t B, int32_t H, int32_t W, void* workspace, int64_t workspace_floats, void* stream);
+
+/* ---- UDIS2 composition stage (the convolutions run on st_conv_gemm with dh/dw) ------------ */
+/* F.interpolate(mode='nearest') to (oh, ow), channels-last rows, C % 4 == 0 (Composition/network.py:70).   */
+int st_resize_nearest_rows(const float* x, int32_t ldx, float* out, int32_t ldo, int32_t B, int32_t H, int32_t W,
+                           int32_t C, int32_t oh, int32_t ow, void* stream);
+/* out = a - b on [rows, C] row views (network.py:120-124).                                                 */
+int st_sub_rows(const float* a, int32_t lda, const float* b, int32_t ldb, float* out, int32_t ldo, int64_t rows,
+                int32_t C, void* stream);
+/* build_model (network.py:8-22): NCHW [B,3,H,W] images / masks, net_out rows [B*H*W] with stride ld_net.    */
+int st_compose_blend(const float* warp1, const float* warp2, const float* mask1, const float* mask2,
+                     const float* net_out, int32_t ld_net, float* learned_mask1, float* learned_mask2,
+                     float* stitched, int32_t B, int32_t H, int32_t W, void* stream);
+/* out.py:284 normalize_fn: clip(0,255)/127.5 - 1.                                                          */
+int st_compose_normalize(const float* x, float* out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,8 @@ SURVEY.md section 8 f-1) on the MI355X package.
 Same flags, `demo.txt` pair list (one directory per line holding input1.jpg / input2.jpg), RGB-float loading and
 result-directory naming as the reference.  The forward (`type="test_out"`) runs on the HIP kernels; its images are
 written as JPEGs.  The TPS / inpainting post-pipeline (core/inference/**, section 8 f-3) is out of scope this round,
-so `ave_fusion.jpg` holds the forward's own `blend_image` (the reference writes the post-TPS blend there)."""
+so `ave_fusion.jpg` holds the forward's own `blend_image` (the reference writes the post-TPS blend there) and the
+composition stage (out.py:277-312, section 8 f-4; `cfg.use_composition`) runs on the forward's canvases."""
 from __future__ import annotations
 
 import argparse
@@ -70,8 +71,8 @@ def to_pillow(t):
 
 
 @torch.no_grad()
-def inference_one_data(cfg, data_dict, save_root_path, warp_model):
-    """out.py:158-275 up to the saves (without the TPS / inpainting post-pipeline)."""
+def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_model=None):
+    """out.py:158-312 up to the saves (without the TPS / inpainting post-pipeline)."""
     from PIL import Image
     path = data_dict["DATA_PATH"]
     name = os.path.basename(os.path.normpath(path))
@@ -90,6 +91,17 @@ def inference_one_data(cfg, data_dict, save_root_path, warp_model):
         m = (out[key] > 0.5)[0, 0].cpu().to(torch.uint8).numpy() * 255
         Image.fromarray(m).save(result_path + key + ".jpg")
     to_pillow(out["blend_image"].float()).save(result_path + "ave_fusion.jpg")
+    if composition_model is not None:
+        # out.py:277-312: learned seam masks + composed image from the UDIS2 composition network
+        import stitch_amd
+        mask1, mask2 = (out["mask1"] > 0.5).float(), (out["mask2"] > 0.5).float()
+        comp = stitch_amd.composition.compose(composition_model, out["output1"], out["output2"], mask1, mask2)
+        st = ((comp["stitched_image"][0] + 1) * 127.5).cpu().numpy().transpose(1, 2, 0).clip(0, 255).astype(np.uint8)
+        Image.fromarray(st).save(result_path + "composition.jpg")
+        for key in ("learned_mask1", "learned_mask2"):
+            lm = (comp[key][0] * 255).cpu().numpy().transpose(1, 2, 0).clip(0, 255).astype(np.uint8)
+            Image.fromarray(lm).save(result_path + key + ".jpg")
+        out = dict(out, **comp)
     return out, result_path
 
 
@@ -103,6 +115,15 @@ def main(argv=None):
     else:
         print("[out.py] no --restore_ckpt given: running with random-init weights (plumbing only)")
     model = model.cuda().eval()
+    composition_model = None
+    if getattr(cfg, "use_composition", False):
+        import stitch_amd
+        path = getattr(cfg, "composition_model_path", "")
+        if path and os.path.exists(path):
+            composition_model, _ = stitch_amd.composition.load_com_model(path)                 # out.py:95-103
+        else:
+            print(f"[out.py] composition checkpoint {path!r} not found: random-init composition network (plumbing only)")
+            composition_model = stitch_amd.composition.Network().cuda().eval()
     model_name = cfg.restore_ckpt.split("/")[-2] if cfg.restore_ckpt.count("/") >= 1 else "random"
     tag = "512" if cfg.resize_to_512 else ""
     tps = cfg.TPS_PIPELINE_CONFIG
@@ -115,7 +136,7 @@ def main(argv=None):
         if cfg.skip_if_avg_fusion_exists and os.path.exists(os.path.join(save_root, os.path.basename(os.path.normpath(dd["DATA_PATH"])), "ave_fusion.jpg")):
             print("[WARNING] Skip, Due to exist", dd["DATA_PATH"])
             continue
-        _, rp = inference_one_data(cfg, dd, save_root, model)
+        _, rp = inference_one_data(cfg, dd, save_root, model, composition_model)
         print("saved", rp)
     return save_root
 

@@ -11,6 +11,7 @@ from .adapter import FlowHomoAdpater, preprocess_occlusion_mask  # noqa: E402,F4
 from .config import CfgNode, load_inference_config, load_model_config  # noqa: E402,F401
 from .flowformer import FlowFormer, build_flowformer  # noqa: E402,F401
 from .homography import UDIS2Network  # noqa: E402,F401
+from . import composition  # noqa: E402,F401
 
 
 def build_model(cfg=None):

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int K = d.K;
+    const int dil_h = d.dh > 1 ? d.dh : 1, dil_w = d.dw > 1 ? d.dw : 1;      // conv dilation (0 / 1 = dense)
     const int kcol = (tid & 7) * 4;   // this thread's float4 column inside a BK chunk
     const int rrow = tid >> 3;        // 0..31
 
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
             const bool kin = k < K;
 #pragma unroll
             for (int p = 0; p < AP; ++p) {
-                const int iy = a_iy0[p] + t_ky, ix = a_ix0[p] + t_kx;
+                const int iy = a_iy0[p] + t_ky * dil_h, ix = a_ix0[p] + t_kx * dil_w;
                 const bool ok = kin && a_pix[p] >= 0 && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
                 const unsigned off = ok ? (unsigned)(((a_b[p] * d.H + iy) * d.W + ix) * d.ldx + t_c) * 4u : ST_OOB;
                 ra[p] = buf_load16(rsrcA, off);
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
                     if (a_pix[p] >= 0 && ke < K) {
                         const int kyx = ke / d.Cin, c = ke - kyx * d.Cin;
                         const int ky = kyx / d.kw, kx = kyx - ky * d.kw;
-                        const int iy = a_iy0[p] + ky, ix = a_ix0[p] + kx;
+                        const int iy = a_iy0[p] + ky * dil_h, ix = a_ix0[p] + kx * dil_w;
                         if (iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
                             x = X[((size_t)(a_b[p] * d.H + iy) * d.W + ix) * d.ldx + c];
                     }
@@ -544,10 +545,11 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     }
     unsigned soffA = (unsigned)i_c0 * 4u, soffB = (unsigned)kt0 * 128u;
     auto set_tap = [&]() {                          // per-lane source offsets of the A pieces for tap (i_ky, i_kx)
-        const int tapbase = (i_ky * d.W + i_kx) * d.ldx;
+        const int ty = i_ky * (d.dh > 1 ? d.dh : 1), tx = i_kx * (d.dw > 1 ? d.dw : 1);      // dilated tap offset
+        const int tapbase = (ty * d.W + tx) * d.ldx;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const bool ok = (unsigned)(a_iy0[i] + i_ky) < (unsigned)d.H && (unsigned)(a_ix0[i] + i_kx) < (unsigned)d.W;
+            const bool ok = (unsigned)(a_iy0[i] + ty) < (unsigned)d.H && (unsigned)(a_ix0[i] + tx) < (unsigned)d.W;
             voffA[i] = ok ? (unsigned)(a_base[i] + tapbase) * 4u : ST_OOB;
         }
     };
@@ -760,6 +762,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x6_kernel(const st_gemm_des
     const int tile_n = bid % ntn, tile_m = bid / ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int K = d.K;
+    const int dil_h = d.dh > 1 ? d.dh : 1, dil_w = d.dw > 1 ? d.dw : 1;      // conv dilation (0 / 1 = dense)
     const int kcol = (tid % TPR) * 4;
     const int rrow = tid / TPR;
     constexpr int AP = BM / RPP, BP = BN / RPP;
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16x6_kernel(const st_gemm_des
         const bool kin = k < K;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            const int iy = a_iy0[p] + t_ky, ix = a_ix0[p] + t_kx;
+            const int iy = a_iy0[p] + t_ky * dil_h, ix = a_ix0[p] + t_kx * dil_w;
             const bool ok = kin && a_ok[p] && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
             const unsigned off = ok ? (unsigned)(((a_b[p] * d.H + iy) * d.W + ix) * d.ldx + t_c) * 4u : ST_OOB;
             ra[p] = buf_load16(rsrcA, off);
@@ -919,10 +922,10 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const st_gemm_desc d) 
 #pragma unroll
     for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
     for (int ky = 0; ky < d.kh; ++ky) {
-        const int iy = oy * d.sh - d.ph + ky;
+        const int iy = oy * d.sh - d.ph + ky * (d.dh > 1 ? d.dh : 1);
         if (iy < 0 || iy >= d.H) continue;
         for (int kx = 0; kx < d.kw; ++kx) {
-            const int ix = ox * d.sw - d.pw + kx;
+            const int ix = ox * d.sw - d.pw + kx * (d.dw > 1 ? d.dw : 1);
             if (ix < 0 || ix >= d.W) continue;
             const float* xr = d.a + ((size_t)(b * d.H + iy) * d.W + ix) * d.ldx;
             const float* wr = d.w + (size_t)(ky * d.kw + kx) * d.Cin;

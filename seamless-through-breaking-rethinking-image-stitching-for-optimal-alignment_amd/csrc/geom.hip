@@ -273,7 +273,8 @@ extern "C" int st_flow_warp(const float* x, const float* flow, const float* mul,
 // ---------------------------------------------------------------------------------------------
 // Bilinear resize of NCHW planes (F.interpolate): align_corners=1 for resize_flow
 // (core/warp_utils.py:38-46, per-channel divisors), =0 for torchvision Resize((512,512)) without
-// antialias (flowHomoAdpater.py:14,204-205).  div[c % ndiv] divides channel c afterwards.
+// antialias (flowHomoAdpater.py:14,204-205).  div[c % ndiv] divides channel c afterwards.  align_corners == 2: the
+// scale_factor form of out.py:281 (source step = (div0, div1) = 1/scale_factor, half-pixel centres, no division).
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ out, int planes,
                                                               int H, int W, int oh, int ow, int align, float div0, float div1,
                                                               int ndiv) {
@@ -282,11 +283,12 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     const int p = blockIdx.z;
     if (i >= oh || j >= ow) return;
     float sy, sx;
-    if (align) {
+    if (align == 1) {
         const float rh = oh > 1 ? (float)(H - 1) / (float)(oh - 1) : 0.f, rw = ow > 1 ? (float)(W - 1) / (float)(ow - 1) : 0.f;
         sy = rh * (float)i; sx = rw * (float)j;
     } else {
-        const float rh = (float)H / (float)oh, rw = (float)W / (float)ow;
+        // align == 2: F.interpolate(scale_factor=s) -- ATen steps the source by 1/s (passed in div0 / div1), not by H/oh
+        const float rh = align == 2 ? div0 : (float)H / (float)oh, rw = align == 2 ? div1 : (float)W / (float)ow;
         sy = rh * ((float)i + 0.5f) - 0.5f; sx = rw * ((float)j + 0.5f) - 0.5f;
         if (sy < 0.f) sy = 0.f;
         if (sx < 0.f) sx = 0.f;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     const float* im = x + (size_t)p * H * W;
     float v = hy * (hx * im[(size_t)y0 * W + x0] + lx * im[(size_t)y0 * W + x1]) +
               ly * (hx * im[(size_t)y1 * W + x0] + lx * im[(size_t)y1 * W + x1]);
-    if (ndiv > 0) v = v / ((p % ndiv) == 0 ? div0 : div1);
+    if (ndiv > 0 && align != 2) v = v / ((p % ndiv) == 0 ? div0 : div1);
     out[(size_t)p * oh * ow + (size_t)i * ow + j] = v;
 }
 

@@ -78,7 +78,7 @@ class workspace_scope:
 
 
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
-              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, M=None, tile=0, split_k=0, out2=None, precision=None):
+              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, dil=(1, 1), M=None, tile=0, split_k=0, out2=None, precision=None):
     """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
 
     x: 2-D view [rows, Cin] of a channels-last activation; geom=(B,H,W,kh,kw,sh,sw,ph,pw) or None (1x1).
@@ -91,8 +91,8 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
         Ho, Wo = 1, rows
     else:
         B, H, W, kh, kw, sh, sw, ph, pw = geom[:9]
-        Ho = (H + 2 * ph - kh) // sh + 1
-        Wo = (W + 2 * pw - kw) // sw + 1
+        Ho = (H + 2 * ph - dil[0] * (kh - 1) - 1) // sh + 1
+        Wo = (W + 2 * pw - dil[1] * (kw - 1) - 1) // sw + 1
         if len(geom) == 11:            # explicit output size (asymmetric zero padding on the right/bottom)
             Ho, Wo = geom[9], geom[10]
     d.a, d.w, d.c = x.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -113,6 +113,7 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     d.act, d.epi, d.alpha = ACT[act], EPI[epi], alpha
     d.batch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_c = batch, bsa, bsw, bsc
     d.batch_stride_aux1 = bsx1
+    d.dh, d.dw = dil
     d.tile_cfg = tile
     d.precision = GEMM_PRECISION if precision is None else precision
     d.split_k = split_k
@@ -398,4 +399,27 @@ def masked_psnr_ssim(image1, final_warp_output):
     out = torch.empty((B, 2), device=dev, dtype=torch.float64)
     check(lib.st_masked_psnr_ssim(_pc(image1), _p(final_warp_output), final_warp_output.stride(0), _p(valid), _p(partial), _p(out),
                                   B, H, W, _stream()), "st_masked_psnr_ssim")
+    return out
+
+
+# ---- composition stage (csrc/composition.hip) --------------------------------------------------
+def resize_nearest_rows(x, out, B, H, W, Cc, oh, ow):
+    check(lib.st_resize_nearest_rows(_p(x), _ld(x), _p(out), _ld(out), B, H, W, Cc, oh, ow, _stream()), "st_resize_nearest_rows")
+    return out
+
+
+def sub_rows(a, b, out):
+    check(lib.st_sub_rows(_p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), a.shape[0], a.shape[1], _stream()), "st_sub_rows")
+    return out
+
+
+def compose_blend(warp1, warp2, mask1, mask2, net_out, lm1, lm2, stitched):
+    B, _, H, W = warp1.shape
+    check(lib.st_compose_blend(_pc(warp1), _pc(warp2), _pc(mask1), _pc(mask2), _p(net_out), _ld(net_out), _pc(lm1), _pc(lm2),
+                               _pc(stitched), B, H, W, _stream()), "st_compose_blend")
+    return stitched
+
+
+def compose_normalize(x, out):
+    check(lib.st_compose_normalize(_pc(x), _pc(out), x.numel(), _stream()), "st_compose_normalize")
     return out

@@ -163,3 +163,21 @@ def test_end_to_end_test_out_256_config1():
                       ("origin_occlusion_mask", "origin_occ_bits"), ("warp_input2_mask", "warp_mask_bits")]:
         flips = np.unpackbits(_bits(o[key]) ^ g[bits]).sum()
         assert flips <= 64, (key, flips)
+
+
+def test_composition_oracle_matches_reference_golden():
+    """oracle/composition.py against the reference's own Network / build_model output
+    (tests/golden/composition_512x544.npz, written by oracle/ref_harness/make_composition_golden.py)."""
+    import os
+    import numpy as np
+    from oracle import composition as oc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "composition_512x544.npz"))
+    sd = oc.seeded_state_dict(4321)
+    assert list(sd.keys()) == list(g["keys"]) == list(oc.state_spec().keys())
+    o1, o2, m1, m2 = oc.synthetic_inputs(512, 544, 77)
+    assert np.allclose(g["in_checksum"], [float(o1.double().sum()), float(o2.double().sum()), float(m1.sum()), float(m2.sum())])
+    out = oc.compose(sd, o1, o2, m1, m2)
+    net = oc.network(sd, oc.preprocess(o1, False), oc.preprocess(o2, False))
+    assert np.abs(net[0, 0, ::2, ::2].numpy() - g["net_out_sub"]).max() < 1e-6
+    assert np.abs(out["stitched_image"][0, :, ::4, ::4].numpy() - g["stitched_sub"]).max() < 1e-6
+    assert np.abs(out["learned_mask1"][0, :, ::4, ::4].numpy() - g["lm1_sub"]).max() < 1e-6

@@ -179,6 +179,9 @@ def test_out_harness_writes_the_reference_file_set(tmp_path, seeded_sd):
     save_root = outmod.main(["--data_root_path", str(root) + "/", "--restore_ckpt", str(ck)])
     assert "ours__seeded_advanced_uniform_multi_all_img1_with_inpaint_g12" in save_root
     files = sorted(os.listdir(os.path.join(save_root, "demo1")))
-    assert files == sorted(["H_warp.jpg", "flow_warp.jpg", "warp1.jpg", "warp2.jpg", "mask1.jpg", "mask2.jpg", "ave_fusion.jpg"])
+    # the 7 warp-stage JPEGs + the 3 files of the composition stage (out.py:303-312; cfg.use_composition is on in this plugin)
+    assert files == sorted(["H_warp.jpg", "flow_warp.jpg", "warp1.jpg", "warp2.jpg", "mask1.jpg", "mask2.jpg", "ave_fusion.jpg",
+                            "composition.jpg", "learned_mask1.jpg", "learned_mask2.jpg"])
+    assert Image.open(os.path.join(save_root, "demo1", "composition.jpg")).size[0] >= 512      # canvases < 512 are up-scaled
     im = Image.open(os.path.join(save_root, "demo1", "ave_fusion.jpg"))
     assert abs(im.size[0] - 256) < 64 and abs(im.size[1] - 256) < 64
