@@ -102,15 +102,26 @@ __device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, unsign
 // row r of a lane's 16 accumulator registers, relative to the lane's first row
 #define ST_EPI_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
 
+// per-workgroup constants of the epilogue: bias of the lane's columns, the device scalar of ST_EPI_AXPY
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_consts(const st_gemm_desc& d, EpiOperands<TM, TN>& e, int n0, int wn, int li, int split) {
+    const bool raw = split > 1;
+    e.sc = (d.scale_ptr && !raw) ? *d.scale_ptr : 1.0f;
+    const __amdgpu_buffer_rsrc_t rb = epi_rsrc(raw ? nullptr : d.bias, (long long)d.N * 4);
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * TN * 32 + jn * 32 + li;
+        e.bv[jn] = buf_ld(rb, (unsigned)(n < d.N ? n : d.N - 1) * 4u, 0);
+    }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOperands<TM, TN>& e, int m0, int n0, int wm, int wn,
                                                    int li, int lh, int split) {
     const bool raw = split > 1;                                // raw partial sums: nothing to fetch
-    e.sc = (d.scale_ptr && !raw) ? *d.scale_ptr : 1.0f;
     const int half = d.N >> 1;
     const bool zr = d.epi == ST_EPI_ZR;
     const long long M = d.M;
-    const __amdgpu_buffer_rsrc_t rb = epi_rsrc(raw ? nullptr : d.bias, (long long)d.N * 4);
     // aux0 row = (m / div) % mod.  div == 8 without mod (one table row per pixel, 8 latent rows each -- the vertical
     // layers' q / k tables) keeps the SGPR-step form: a lane's rows m0' + (r&3) + 8*(r>>2), m0' % 4 == 0, map to
     // table rows m0'/8 + (r>>2), i.e. four loads.  Other mappings are computed per element (small GEMMs only).
@@ -125,7 +136,6 @@ __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOpe
     for (int jn = 0; jn < TN; ++jn) {
         const int n = n0 + wn * TN * 32 + jn * 32 + li;
         const int nc = n < d.N ? n : d.N - 1;
-        e.bv[jn] = buf_ld(rb, (unsigned)nc * 4u, 0);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row0 = m0 + wm * TM * 32 + i * 32 + 4 * lh;              // this lane's first row
@@ -206,9 +216,24 @@ __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] += e.a0[i][jn][r];
             }
-            if (d.act != ST_ACT_NONE) {
+            switch (d.act) {                                   // wave-uniform, outside the register loop
+                case ST_ACT_RELU:
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = st_act(v[r], d.act);
+                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                    break;
+                case ST_ACT_GELU:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = st_act(v[r], ST_ACT_GELU);
+                    break;
+                case ST_ACT_SIGMOID:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = st_act(v[r], ST_ACT_SIGMOID);
+                    break;
+                case ST_ACT_TANH:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = st_act(v[r], ST_ACT_TANH);
+                    break;
+                default: break;
             }
             if (zr) {
                 const unsigned vc = (ncol && n < half) ? (unsigned)(row0 * d.ldc + n) * 4u : ST_OOB;
@@ -243,6 +268,7 @@ template <int TM, int TN>
 __device__ __forceinline__ void gemm_tile_epilogue(const st_gemm_desc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN], int m0, int n0,
                                                    int wm, int wn, int li, int lh, int split, int kz) {
     EpiOperands<TM, TN> e;
+    gemm_epilogue_consts<TM, TN>(d, e, n0, wn, li, split);
     gemm_epilogue_load<TM, TN>(d, e, m0, n0, wm, wn, li, lh, split);
     gemm_epilogue_store<TM, TN>(d, C, acc, e, m0, n0, wm, wn, li, lh, split, kz);
 }
@@ -630,6 +656,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     // epilogue operands are fetched ahead of the K loop (ordinary loads, older than every DMA of the ring: the
     // counted vmcnt waits below only ever over-wait because of them)
     EpiOperands<TM, TN> eop;
+    gemm_epilogue_consts<TM, TN>(d, eop, n0, wn, li, split);                 // once per workgroup (also for every M tile of PERSIST)
     if (!PERSIST) gemm_epilogue_load<TM, TN>(d, eop, m0, n0, wm, wn, li, lh, split);
     __builtin_amdgcn_sched_barrier(0);
 
