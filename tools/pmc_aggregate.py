@@ -17,7 +17,7 @@ for name, agg in (("FETCH_SIZE", F), ("WRITE_SIZE", W)):
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             f.write(f'"{k}",{n},{v:.0f},{v / n:.1f}\n')
 gemm = [k for k in F if "conv_gemm" in k]
-forwards = F.get("patch_conv1_kernel", [1])[0]
+forwards = max([v[0] for k, v in F.items() if "patch_conv1" in k] or [1])
 launches = sum(F[k][0] for k in gemm)
 fetch = sum(F[k][1] for k in gemm) * 1024 * 2
 write = sum(W[k][1] for k in gemm if k in W) * 1024
