@@ -5,10 +5,17 @@
 // A is an NHWC activation read through convolution addressing (kh x kw window, stride, zero
 // padding); a plain row-major matrix is the 1x1 case.  Wt is [N, K] row-major with
 // K = kh*kw*Cin ordered (ky, kx, c) -- the layout nn.Linear already has and the layout the host
-// prepacks conv weights into.  Both operand tiles are K-contiguous in LDS ([rows][BK+4] floats, the
-// +4 pad makes the 16-B fragment reads conflict-free); each lane fetches 4 consecutive k of its row
-// with one ds_read_b128 and feeds them to 4 consecutive MFMAs, lane half h taking k = 8j+4h+t for
+// prepacks conv weights into.  Both operand tiles are K-contiguous in LDS; each lane fetches 4 consecutive k
+// of its row with one ds_read_b128 and feeds them to 4 consecutive MFMAs, lane half h taking k = 8j+4h+t for
 // both operands so the contraction pairs up without any transposition.
+//
+// Kernels in this file (dispatch: conv_gemm_launch):
+//   conv_gemm_dma_kernel   Cin % 32 == 0 (the default): global -> LDS DMA ring, VALU-free K loop, optional persistent walk
+//                          over M tiles; tiles 64x64 / 128x64 / 128x32
+//   conv_gemm_kernel       any Cin % 4 == 0 (or scalar gather otherwise): register-staged, [rows][BK+4] padded LDS tiles
+//   conv_gemm_bf16x6_kernel opt-in fp32-grade split-bf16 product (precision = 1)
+//   skinny_gemm_kernel (M <= 8), narrow_conv_kernel (N <= 4), splitk_reduce_kernel
+// and one epilogue (bias, alpha, row-mapped addend, activation, residual / gate / GRU / axpy / fused z|r) shared by all.
 //
 // Replaces (reference, /root/reference): every F.conv2d / nn.Linear / einsum contraction on the
 // FlowHomoAdpater path, e.g. core/FlowFormer/PerCostFormer3/encoder.py:359-369 (all-pairs corr),
