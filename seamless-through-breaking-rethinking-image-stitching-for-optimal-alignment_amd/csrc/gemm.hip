@@ -1039,6 +1039,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     st_gemm_desc d = *desc;
     if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
     if (d.kh <= 0 || d.kw <= 0 || d.K != d.kh * d.kw * d.Cin) return ST_EINVAL;
+    if (d.Ho <= 0 || d.Wo <= 0 || d.M % (d.Ho * d.Wo)) return ST_EINVAL;
     if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
@@ -1046,17 +1047,58 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     // byte extents of one batch slice of A and W for the buffer descriptors (must stay below 2 GiB so the
     // out-of-range sentinel offset is always past num_records)
     {
-        const int64_t a_rows = (int64_t)(d.M / (d.Ho * d.Wo)) * d.H * d.W;
-        const int64_t ab = ((a_rows - 1) * d.ldx + d.Cin) * 4, wb = ((int64_t)(d.N - 1) * d.ldw + d.K) * 4;
-        if (ab >= (int64_t)ST_OOB || wb >= (int64_t)ST_OOB) return ST_EINVAL;
+        const bool plain_mat = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && (int64_t)d.H * d.W == d.M &&
+                               (int64_t)d.Ho * d.Wo == d.M;          // a matrix: every row is its own "image"
+        const int64_t hw = plain_mat ? 1 : (int64_t)d.Ho * d.Wo, nimg = d.M / hw, img_rows = plain_mat ? 1 : (int64_t)d.H * d.W;
+        const int64_t ab = ((nimg * img_rows - 1) * d.ldx + d.Cin) * 4, wb = ((int64_t)(d.N - 1) * d.ldw + d.K) * 4;
+        if (wb >= (int64_t)ST_OOB) return ST_EINVAL;
         // the epilogue addresses C / aux operands with 32-bit buffer offsets (first row of a lane + SGPR row step)
-        const int64_t lim = (int64_t)1 << 31, rows = (int64_t)d.M + 256;
+        const int64_t lim = (int64_t)1 << 31;
         int64_t ldmax = d.ldc > d.N ? d.ldc : d.N;
         if (d.aux0 && d.ld_aux0 > ldmax) ldmax = d.ld_aux0;
         if (d.aux1 && d.ld_aux1 > ldmax) ldmax = d.ld_aux1;
         if (d.aux2 && d.ld_aux2 > ldmax) ldmax = d.ld_aux2;
         if (d.c2 && d.ldc2 > ldmax) ldmax = d.ldc2;
-        if (rows * ldmax * 4 >= lim) return ST_EINVAL;
+        if (ab >= (int64_t)ST_OOB || ((int64_t)d.M + 256) * ldmax * 4 >= lim) {
+            // Larger than the 32-bit offsets reach (whole-batch PatchEmbed maps at B >= 4, ...): run the rows in chunks.
+            // A chunk is a whole number of images (convs) and of aux0 mapping periods, so every operand just shifts its base.
+            if ((d.batch > 1) || d.split_k > 1) return ST_EINVAL;
+            const int64_t div = d.aux0_row_div > 1 ? d.aux0_row_div : 1, mod = d.aux0_row_mod > 0 ? d.aux0_row_mod : 1;
+            int64_t unit = hw;                                           // rows per indivisible unit
+            {
+                const int64_t period = div * mod;                       // lcm(unit, period) via gcd
+                int64_t a = unit, b = period;
+                while (b) { const int64_t t = a % b; a = b; b = t; }
+                unit = unit / a * period;
+            }
+            const int64_t in_rows_per_unit = unit / hw * img_rows;
+            int64_t per_out = (lim / 4 / ldmax - 256) / unit, per_in = ((int64_t)ST_OOB / 4 / d.ldx) / in_rows_per_unit;
+            int64_t units = per_out < per_in ? per_out : per_in;
+            // strictly inside both limits (the same tests as above, on the chunk)
+            while (units > 0 && (((units * in_rows_per_unit - 1) * d.ldx + d.Cin) * 4 >= (int64_t)ST_OOB ||
+                                 (units * unit + 256) * ldmax * 4 >= lim))
+                --units;
+            if (units < 1 || d.M % unit || units * unit >= d.M) return ST_EINVAL;      // (a chunk must be a strict part)
+            {
+                const int64_t total = d.M / unit, nchunks = (total + units - 1) / units;  // equal-sized chunks
+                units = (total + nchunks - 1) / nchunks;
+            }
+            const int64_t chunk = units * unit;
+            for (int64_t m0 = 0; m0 < d.M; m0 += chunk) {
+                st_gemm_desc c = *desc;
+                c.M = (int32_t)((d.M - m0) < chunk ? (d.M - m0) : chunk);
+                c.a = d.a + m0 / hw * img_rows * d.ldx;
+                c.c = d.c + m0 * d.ldc;
+                if (d.c2) c.c2 = d.c2 + m0 * d.ldc2;
+                if (d.aux1) c.aux1 = d.aux1 + m0 * d.ld_aux1;
+                if (d.aux2) c.aux2 = d.aux2 + m0 * d.ld_aux2;
+                if (d.aux0 && d.aux0_row_mod <= 0) c.aux0 = d.aux0 + m0 / div * d.ld_aux0;   // with a modulus the chunk starts a period
+                if (plain_mat) { c.H = 1; c.W = c.M; c.Ho = 1; c.Wo = c.M; }
+                const int rc = conv_gemm_launch(&c, stream);
+                if (rc) return rc;
+            }
+            return ST_OK;
+        }
         d.a_bytes = (uint32_t)ab; d.w_bytes = (uint32_t)wb;
     }
     const bool aligned = ((uintptr_t)d.a % 16 == 0) && ((uintptr_t)d.w % 16 == 0) && (d.ldx % 4 == 0) &&

@@ -185,3 +185,49 @@ def test_out_harness_writes_the_reference_file_set(tmp_path, seeded_sd):
     assert Image.open(os.path.join(save_root, "demo1", "composition.jpg")).size[0] >= 512      # canvases < 512 are up-scaled
     im = Image.open(os.path.join(save_root, "demo1", "ave_fusion.jpg"))
     assert abs(im.size[0] - 256) < 64 and abs(im.size[1] - 256) < 64
+
+
+def test_gemm_beyond_32bit_offsets_runs_in_chunks():
+    """Operands larger than the 2 GiB a buffer descriptor / 32-bit epilogue offset reaches (whole-batch PatchEmbed maps at
+    B >= 4) are processed in row chunks that shift every operand's base: same bits as the small calls."""
+    import stitch_amd
+    ops = stitch_amd.ops
+    g = torch.Generator().manual_seed(0)
+    # conv: 160 images of 64x64 inside a 1024-wide row buffer -> A extent 2.7 GB
+    B, H, W, C, ld = 160, 64, 64, 32, 1024
+    xw = torch.empty(B * H * W, ld, device="cuda")
+    xw[:, 8:8 + C] = torch.randn(B * H * W, C, generator=g).cuda()
+    w = (torch.randn(24, 9 * C, generator=g) / (9 * C) ** 0.5).cuda()
+    res = torch.randn(B * H * W, 24, generator=g).cuda()
+    out = torch.empty(B * H * W, 24, device="cuda")
+    ops.conv_gemm(xw[:, 8:8 + C], w, out, geom=(B, H, W, 3, 3, 1, 1, 1, 1), act="relu", epi="add", aux1=res)
+    for b0 in (0, 77, 159):
+        rows = slice(b0 * H * W, (b0 + 1) * H * W)
+        ref = torch.empty(H * W, 24, device="cuda")
+        ops.conv_gemm(xw[rows, 8:8 + C], w, ref, geom=(1, H, W, 3, 3, 1, 1, 1, 1), act="relu", epi="add", aux1=res[rows])
+        assert torch.equal(out[rows], ref)
+    del xw, out, res
+    # plain matrix with a (row / 8) % 40 addend table: output 4.4M x 128 fp32 = 2.25 GB
+    M, K, N = 4_400_000, 64, 128
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / 8).cuda()
+    tab = torch.randn(40, N, generator=g).cuda()
+    out = torch.empty(M, N, device="cuda")
+    ops.conv_gemm(x, w, out, aux0=tab, row_div=8, row_mod=40)
+    for m0 in (0, 2_999_680, M - 640):          # multiples of 8*40
+        ref = torch.empty(640, N, device="cuda")
+        ops.conv_gemm(x[m0:m0 + 640], w, ref, aux0=tab, row_div=8, row_mod=40)
+        assert torch.equal(out[m0:m0 + 640], ref)
+
+
+def test_batch_of_four_pairs_runs_and_matches_single(model):
+    """evaluate.py feeds batches (bs 12 in the reference): B=4 pairs = 8 FlowFormer samples = 32768 cost maps, whose
+    PatchEmbed activations exceed 2 GiB and go through the chunked GEMM path.  Sample 2 of the batch vs the same pair alone."""
+    pairs = [inputs.structured_pair(512, 512, seed=60 + i, shift=(2 * i - 3, 5 - i)) for i in range(4)]
+    A, Bm = torch.cat([p[0] for p in pairs]).cuda(), torch.cat([p[1] for p in pairs]).cuda()
+    fwd, bwd = model.predict_flow_pair(A, Bm)
+    assert fwd.shape == (4, 2, 512, 512) and torch.isfinite(fwd).all() and torch.isfinite(bwd).all()
+    f1, b1 = model.predict_flow_pair(pairs[2][0].cuda(), pairs[2][1].cuda())
+    assert (fwd[2] - f1[0]).abs().max() < 1e-1 and (bwd[2] - b1[0]).abs().max() < 1e-1
+    o = model(A, Bm, type="test_eval")
+    assert o["final_warp_output"].shape == (4, 6, 512, 512) and torch.isfinite(o["final_warp_output"]).all()
