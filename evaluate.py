@@ -1,0 +1,57 @@
+"""UDIS-D evaluation harness (re-statement of the reference's evaluate.py:110-152) on the MI355X
+package: same flags, `configs.<model_config_name>.config_dict`, strict checkpoint load, masked PSNR / SSIM, easy / mid / hard
+split.  One process per GPU instead of nn.DataParallel:
+
+    python evaluate.py --ckpt_path ./checkpoints/final_ckpt --data_dir ./data/UDIS/UDIS-D/ [--batch_size 12]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 evaluate.py ...      # pairs sharded over ranks
+
+The metric runs on the GPU (`st_masked_psnr_ssim`); the per-pair values are all-gathered once (RCCL) and every rank holds the
+full table, rank 0 prints the reference's result dict."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def validate(cfg, val_dataset, batch_size=1):
+    """evaluate.py:110-128."""
+    import stitch_amd
+    from stitch_amd import evaluate as sev
+    assert cfg.restore_ckpt is not None, "Please specify the checkpoint using in restore_ckpt"
+    if not (hasattr(cfg, "homo_backbone") and cfg.homo_backbone is not None):
+        raise NotImplementedError
+    model = stitch_amd.build_model(cfg)
+    print("[Loading ckpt from {}]".format(cfg.restore_ckpt))
+    model.load_state_dict(torch.load(cfg.restore_ckpt, map_location="cpu", weights_only=True), strict=True)
+    model = model.cuda().eval()
+    return sev.validate_with_model(model, val_dataset, batch_size=batch_size)[0]
+
+
+def main(argv=None):
+    import stitch_amd
+    from stitch_amd import dist as sdist, evaluate as sev
+    p = argparse.ArgumentParser()
+    p.add_argument("--ckpt_path", type=str, default="./checkpoints/final_ckpt", help="ckpt path")
+    p.add_argument("--model_config_name", type=str, default="last_config", help="model config")
+    p.add_argument("--data_dir", type=str, default="./data/UDIS/UDIS-D/", help="data dir")
+    p.add_argument("--batch_size", type=int, default=1, help="pairs per forward (the reference's loader uses 12)")
+    args = p.parse_args(argv)
+    rank, world, local = sdist.init()
+    torch.cuda.set_device(local)
+    cfg = stitch_amd.load_model_config(args.model_config_name)
+    cfg.batch_size = 1
+    cfg.restore_ckpt = args.ckpt_path
+    val_dataset = sev.UDISDataset(data_dir=args.data_dir, phase="testing")
+    result = validate(cfg, val_dataset, batch_size=args.batch_size)
+    if rank == 0:
+        print(result)
+    return result
+
+
+if __name__ == "__main__":
+    main()

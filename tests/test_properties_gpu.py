@@ -156,6 +156,17 @@ def test_validate_with_model_harness(model, tmp_path):
     res, table = ev.validate_with_model(model, ds, batch_size=2)
     assert set(res) == {"avg_psnr", "avg_ssim", "easy_psnr", "mid_psnr", "hard_psnr", "easy_ssim", "mid_ssim", "hard_ssim"}
     assert table.shape == (3, 2) and torch.isfinite(table).all() and 0 < res["avg_ssim"] <= 1.0
+    # the root evaluate.py CLI (reference flags, evaluate.py:130-152) drives the same harness from a checkpoint file
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location("stitch_eval_cli", os.path.join(root, "evaluate.py"))
+    cli = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(cli)
+    ck = tmp_path / "final_ckpt"
+    torch.save({"module." + k: v for k, v in model.state_dict().items()}, str(ck))
+    res2 = cli.main(["--ckpt_path", str(ck), "--data_dir", str(tmp_path) + "/", "--batch_size", "3"])
+    assert set(res2) == set(res) and abs(res2["avg_psnr"] - res["avg_psnr"]) < 0.5
 
 
 def test_out_harness_writes_the_reference_file_set(tmp_path, seeded_sd):
