@@ -7,7 +7,9 @@ lib, GemmDesc = stitch_amd._lib.lib, stitch_amd._lib.GemmDesc
 cfg, _ = stitch_amd.load_inference_config("all_img1_with_inpaint_g12_transRef")
 torch.manual_seed(1234)
 model = stitch_amd.build_model(cfg).cuda().eval()
-a, b = inputs.structured_pair(512, 512, seed=7); a, b = a.cuda(), b.cuda()
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+pairs = [inputs.structured_pair(512, 512, seed=7 + i) for i in range(NB)]
+a, b = torch.cat([p[0] for p in pairs]).cuda(), torch.cat([p[1] for p in pairs]).cuda()
 for _ in range(2): model(a, b, type="test_eval")
 rec, open_ev = [], []
 
