@@ -38,9 +38,48 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// C == 128 (every LayerNorm of the cost encoder / vertical layers, 65536 x 128 and up: pure HBM streaming): half a
+// wave per row with one 16-B load per lane, four rows per thread issued before the first reduction so that each wave
+// keeps 4 KiB in flight instead of 512 B.
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void layernorm128_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ out, int ldo,
+                                                           int rows, float eps) {
+    constexpr int R = 4;                                   // rows per thread; a workgroup covers 8 * R rows
+    const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int row0 = blockIdx.x * (8 * R) + sub;
+    float4 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + 8 * r;
+        v[r] = row < rows ? *reinterpret_cast<const float4*>(x + (size_t)row * ldx + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 wv = *reinterpret_cast<const float4*>(w + 4 * l), bv = *reinterpret_cast<const float4*>(b + 4 * l);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + 8 * r;
+        const float mean = half_wave_sum((v[r].x + v[r].y) + (v[r].z + v[r].w)) * (1.0f / 128.0f);
+        const float dx = v[r].x - mean, dy = v[r].y - mean, dz = v[r].z - mean, dw = v[r].w - mean;
+        const float rstd = 1.0f / sqrtf(half_wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 128.0f) + eps);
+        if (row < rows)
+            *reinterpret_cast<float4*>(out + (size_t)row * ldo + 4 * l) =
+                make_float4(dx * rstd * wv.x + bv.x, dy * rstd * wv.y + bv.y, dz * rstd * wv.z + bv.z, dw * rstd * wv.w + bv.w);
+    }
+}
+
 extern "C" int st_layernorm(const float* x, int32_t ldx, const float* w, const float* b, float* out, int32_t ldo,
                             int32_t rows, int32_t C, float eps, void* stream) {
     if (!x || !w || !b || !out || rows <= 0 || C <= 0 || C > 1024) return ST_EINVAL;
+    if (C == 128 && !(ldx & 3) && !(ldo & 3) && !(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b) & 15)) {
+        hipLaunchKernelGGL(layernorm128_kernel, dim3((rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, out, ldo,
+                           rows, eps);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, out,
                        ldo, rows, C, eps);
     ST_CHECK_LAUNCH();
