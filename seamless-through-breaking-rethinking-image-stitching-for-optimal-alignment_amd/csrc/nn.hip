@@ -441,14 +441,128 @@ __global__ __launch_bounds__(256) void attention_kvlds_kernel(const float* __res
     }
 }
 
+// The same attention on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) for Nk % 16 == 0, Nk <= 256.
+// A wave takes 16 queries at a time:
+//   S^T[key, query] = K . Q^T   one 16x16 tile per 16 keys, D/4 MFMAs each; the tile lands with the QUERY in the lane's
+//                               column, so a lane holds Nk/4 scores of one query and the softmax is register-local apart from
+//                               two shuffles (max, sum) across the four 16-lane groups
+//   O^T[d, query]   = V^T . P^T the probabilities are already in the B-operand layout (lane = query column, register =
+//                               k slot); V^T fragments are single ds_read_b32 from a [key][D+4] slab (conflict-free)
+// The k slot <-> dim / key assignment inside a 4-deep MFMA step is free as long as both operands agree: dims are taken
+// as g*(D/4)+s (one or two 16-B reads per lane), keys as 16*kt + 4*g + s (the accumulator layout of S^T).
+// The VALU formulation above issues ~2x(16+16) FMAs + bookkeeping per (query, key) on the datapath the MFMA shares, at
+// roughly 40 % of the FMA peak; here the same products cost D/2 MFMA cycles per (query, key) and the VALU only does the exp.
+typedef float kv_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_kv_mfma_kernel(const float* __restrict__ q, long q_bs, long q_ts,
+                                                                const float* __restrict__ k, long k_bs, long k_ts,
+                                                                const float* __restrict__ v, long v_bs, long v_ts,
+                                                                float* __restrict__ out, long o_bs, long o_ts, int Nq, int Nk,
+                                                                float scale, int tiles_per_wave) {
+    constexpr int LD = D + 4;                       // slab row stride (floats): conflict-free V^T reads, 16-B aligned K reads
+    constexpr int DS = D / 4;                       // MFMA steps over the head dim; also dims per k slot
+    constexpr int DB = D / 16;                      // 16-row blocks of O^T
+    constexpr int MAXT = 16;                        // Nk <= 256
+    extern __shared__ __attribute__((aligned(16))) float kv[];
+    const int h = blockIdx.y, b = blockIdx.z;
+    float* Ks = kv;
+    float* Vs = kv + (size_t)Nk * LD;
+    for (int i = threadIdx.x; i < Nk * (D / 4); i += 256) {
+        const int j = i / (D / 4), e = (i % (D / 4)) * 4;
+        *reinterpret_cast<float4*>(Ks + j * LD + e) = *reinterpret_cast<const float4*>(k + b * k_bs + j * k_ts + h * D + e);
+        *reinterpret_cast<float4*>(Vs + j * LD + e) = *reinterpret_cast<const float4*>(v + b * v_bs + j * v_ts + h * D + e);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int nkt = Nk >> 4;
+    const float* Kl = Ks + c * LD + g * DS;         // + 16*kt*LD: this lane's K fragment (DS consecutive dims)
+    const float* Vl = Vs + (4 * g) * LD + c;        // + (16*kt + s)*LD (+16 for the second d block)
+    for (int t = 0; t < tiles_per_wave; ++t) {
+        const int q0 = ((blockIdx.x * 4 + wave) * tiles_per_wave + t) * 16;
+        if (q0 >= Nq) break;                        // wave-uniform
+        const int qi = min(q0 + c, Nq - 1);
+        float qf[DS];
+        {
+            const float* qp = q + b * q_bs + (long)qi * q_ts + h * D + g * DS;
+#pragma unroll
+            for (int e = 0; e < DS; e += 4) {
+                const float4 tq = *reinterpret_cast<const float4*>(qp + e);
+                qf[e] = tq.x * scale; qf[e + 1] = tq.y * scale; qf[e + 2] = tq.z * scale; qf[e + 3] = tq.w * scale;
+            }
+        }
+        kv_f32x4 sc[MAXT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt < nkt) {
+                float kf[DS];
+#pragma unroll
+                for (int e = 0; e < DS; e += 4) {
+                    const float4 tk = *reinterpret_cast<const float4*>(Kl + kt * 16 * LD + e);
+                    kf[e] = tk.x; kf[e + 1] = tk.y; kf[e + 2] = tk.z; kf[e + 3] = tk.w;
+                }
+                kv_f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < DS; ++e) a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[e], a, 0, 0, 0);
+                sc[kt] = a;
+                mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+        kv_f32x4 o[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] = kv_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt < nkt) {
+                kv_f32x4 p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p[r] = __expf(sc[kt][r] - mx); sum += p[r]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int db = 0; db < DB; ++db)
+                        o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vl[(kt * 16 + r) * LD + 16 * db], p[r], o[db], 0, 0, 0);
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (q0 + c < Nq) {
+            float* op = out + b * o_bs + (long)(q0 + c) * o_ts + h * D + 4 * g;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+                *reinterpret_cast<float4*>(op + 16 * db) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
+        }
+    }
+}
+
 extern "C" int st_attention_kvlds(const float* q, int64_t q_bs, int64_t q_ts, const float* k, int64_t k_bs, int64_t k_ts,
                                   const float* v, int64_t v_bs, int64_t v_ts, float* out, int64_t o_bs, int64_t o_ts,
                                   int32_t B, int32_t heads, int32_t Nq, int32_t Nk, int32_t D, float scale, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if ((D == 16 || D == 32) && Nk % 16 == 0 && Nk <= 256 && !((q_ts | k_ts | v_ts | o_ts | q_bs | k_bs | v_bs | o_bs) & 3)) {
+        const int tpw = 4;                                       // 16-query tiles per wave: 256 queries per workgroup
+        const size_t ldsm = (size_t)2 * Nk * (D + 4) * sizeof(float);
+        dim3 gridm((Nq + 64 * tpw - 1) / (64 * tpw), heads, B);
+        if (D == 16)
+            hipLaunchKernelGGL(attention_kv_mfma_kernel<16>, gridm, dim3(256), ldsm, s, q, q_bs, q_ts, k, k_bs, k_ts, v, v_bs, v_ts, out,
+                               o_bs, o_ts, Nq, Nk, scale, tpw);
+        else
+            hipLaunchKernelGGL(attention_kv_mfma_kernel<32>, gridm, dim3(256), ldsm, s, q, q_bs, q_ts, k, k_bs, k_ts, v, v_bs, v_ts, out,
+                               o_bs, o_ts, Nq, Nk, scale, tpw);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     const size_t lds = (size_t)2 * Nk * D * sizeof(float);
     if (lds > 160 * 1024) return ST_EINVAL;
     dim3 grid((Nq + 511) / 512, heads, B), block(256);
-    hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_AK(DD)                                                                                                   \
     do {                                                                                                                \
         auto kern = attention_kvlds_kernel<DD>;                                                                         \
