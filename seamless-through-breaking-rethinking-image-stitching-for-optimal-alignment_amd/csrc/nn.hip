@@ -489,7 +489,9 @@ __global__ __launch_bounds__(256) void attention_kv_mfma_kernel(const float* __r
 #pragma unroll
             for (int e = 0; e < DS; e += 4) {
                 const float4 tq = *reinterpret_cast<const float4*>(qp + e);
-                qf[e] = tq.x * scale; qf[e + 1] = tq.y * scale; qf[e + 2] = tq.z * scale; qf[e + 3] = tq.w * scale;
+                // scores are kept in the log2 domain (scale * log2 e folded into Q): the softmax is then a bare v_exp_f32
+                const float sl = scale * 1.44269504088896340736f;
+                qf[e] = tq.x * sl; qf[e + 1] = tq.y * sl; qf[e + 2] = tq.z * sl; qf[e + 3] = tq.w * sl;
             }
         }
         kv_f32x4 sc[MAXT];
@@ -513,26 +515,30 @@ __global__ __launch_bounds__(256) void attention_kv_mfma_kernel(const float* __r
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
-        kv_f32x4 o[DB];
+        kv_f32x4 o[DB], o2[DB];                     // two accumulation chains (keys r even / odd), folded at the end
 #pragma unroll
-        for (int db = 0; db < DB; ++db) o[db] = kv_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int db = 0; db < DB; ++db) { o[db] = kv_f32x4{0.f, 0.f, 0.f, 0.f}; o2[db] = kv_f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int kt = 0; kt < MAXT; ++kt) {
             if (kt < nkt) {
                 kv_f32x4 p;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { p[r] = __expf(sc[kt][r] - mx); sum += p[r]; }
+                for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[kt][r] - mx); sum += p[r]; }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int db = 0; db < DB; ++db)
-                        o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vl[(kt * 16 + r) * LD + 16 * db], p[r], o[db], 0, 0, 0);
+                    for (int db = 0; db < DB; ++db) {
+                        if (r & 1) o2[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vl[(kt * 16 + r) * LD + 16 * db], p[r], o2[db], 0, 0, 0);
+                        else o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vl[(kt * 16 + r) * LD + 16 * db], p[r], o[db], 0, 0, 0);
+                    }
                 }
             }
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] += o2[db];
         if (q0 + c < Nq) {
             float* op = out + b * o_bs + (long)(q0 + c) * o_ts + h * D + 4 * g;
 #pragma unroll
@@ -548,7 +554,7 @@ extern "C" int st_attention_kvlds(const float* q, int64_t q_bs, int64_t q_ts, co
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if ((D == 16 || D == 32) && Nk % 16 == 0 && Nk <= 256 && !((q_ts | k_ts | v_ts | o_ts | q_bs | k_bs | v_bs | o_bs) & 3)) {
-        const int tpw = 4;                                       // 16-query tiles per wave: 256 queries per workgroup
+        const int tpw = Nq >= 8192 ? 4 : 2;                       // 16-query tiles per wave (K/V staging amortised over 128..256 queries)
         const size_t ldsm = (size_t)2 * Nk * (D + 4) * sizeof(float);
         dim3 gridm((Nq + 64 * tpw - 1) / (64 * tpw), heads, B);
         if (D == 16)
