@@ -125,6 +125,13 @@ int st_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t ro
 int st_prep_image(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t ldo,
                   float mul, float div, float sub, void* stream);
 
+/* Latent cross-attention with the k / v projections folded out (crossattentionlayer.py:37-56, attention.py:9-68; the 8
+ * latent queries do not depend on the pixel): per pixel, softmax over its P tokens of the 64 (latent, head) score rows
+ * and the pooling z = softmax(S)^T . T.  scores [pixels*P, ld_s>=64] (col = latent*8 + head), tokens [pixels*P, ld_t>=128],
+ * z [pixels*64, 128].  P even, <= 64.                                                                        */
+int st_latent_pool(const float* scores, int32_t ld_s, const float* tokens, int32_t ld_t, float* z, int32_t pixels,
+                   int32_t P, void* stream);
+
 /* ---- FlowFormer decoder gathers --------------------------------------------------------------- */
 int st_coords_grid(float* out, int32_t B, int32_t H, int32_t W, void* stream);          /* decoder.py:22-29 */
 int st_flow_from_coords(const float* coords1, float* flow4, int32_t ld4, float* dst2, int32_t ld2, int32_t B,

@@ -340,6 +340,79 @@ extern "C" int st_attention_small(const float* q, int64_t q_bs, int64_t q_ts, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// Latent cross-attention with pixel-independent queries (crossattentionlayer.py:37-56 + attention.py:9-68, first layer of
+// the cost encoder): the 8 latent queries are the same for every pixel, so  q.(Wk t + bk) = (Wk^T q).t + const  and the
+// constant cancels in the softmax; likewise  sum_t p_t (Wv t + bv) = Wv (sum_t p_t t) + bv.  The host therefore takes the
+// scores against the un-projected patch tokens (one N = 64 GEMM with the folded queries) and this kernel does the rest
+// per pixel: softmax over the P tokens for each of the 64 (latent, head) rows and the pooling z = softmax(S)^T . T
+// (64 x P x 128) on v_mfma_f32_32x32x2_f32 -- operands go straight from L2 into the fragment registers (a lane needs exactly
+// S[tok][row] and T[tok][col], both coalesced), no LDS, no barrier.  The per-pixel K|V tensor of the reference (P x 256
+// floats per pixel: 537 MB at 512^2) is never materialised.
+//   scores [pixels*P, ld_s >= 64] (row = (pixel, token), col = latent*8 + head), tokens [pixels*P, ld_t >= 128],
+//   z [pixels*64, 128] (row = (pixel, latent, head)).  P even, P <= 64.
+typedef float lp_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void latent_pool_kernel(const float* __restrict__ scores, int ld_s, const float* __restrict__ tokens,
+                                                          int ld_t, float* __restrict__ z, int P) {
+    const size_t pix = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ib = wave & 1, jb0 = (wave >> 1) * 2;            // this wave: rows [32*ib, +32), column blocks jb0, jb0+1
+    const float* Sp = scores + pix * P * ld_s + ib * 32 + li;  // + tok*ld_s
+    const float* Tp = tokens + pix * P * ld_t + jb0 * 32 + li; // + tok*ld_t (+32 for the second block)
+    const int steps = P >> 1;                                  // MFMA k = 2: tokens 2s + lh
+    float a[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        a[s] = s < steps ? Sp[(size_t)(2 * s + lh) * ld_s] : -INFINITY;
+        mx = fmaxf(mx, a[s]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) { a[s] = __expf(a[s] - mx); sum += a[s]; }       // exp(-inf) = 0 for the unused steps
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    lp_f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int s0 = 0; s0 < 32; s0 += 8) {
+        if (s0 < steps) {                                      // wave-uniform
+            float b0[8], b1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int tok = min(2 * (s0 + u) + lh, P - 1);
+                b0[u] = Tp[(size_t)tok * ld_t];
+                b1[u] = Tp[(size_t)tok * ld_t + 32];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float av = a[s0 + u] * inv;              // 0 beyond P
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[u], acc1, 0, 0, 0);
+            }
+        }
+    }
+    float* zp = z + (pix * 64 + ib * 32 + 4 * lh) * 128 + jb0 * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        zp[(size_t)row * 128] = acc0[r];
+        zp[(size_t)row * 128 + 32] = acc1[r];
+    }
+}
+
+extern "C" int st_latent_pool(const float* scores, int32_t ld_s, const float* tokens, int32_t ld_t, float* z, int32_t pixels,
+                              int32_t P, void* stream) {
+    if (!scores || !tokens || !z || pixels <= 0 || P <= 0 || (P & 1) || P > 64 || ld_s < 64 || ld_t < 128) return ST_EINVAL;
+    hipLaunchKernelGGL(latent_pool_kernel, dim3(pixels), dim3(256), 0, (hipStream_t)stream, scores, ld_s, tokens, ld_t, z, P);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Global sub-sampled attention (GSA, twins.py:336-392,633-680): many queries against <= 256
 // pooled keys.  The (batch, head) K/V slab is staged once in LDS and every thread owns one query
 // (online softmax); LDS reads are wave-uniform broadcasts.

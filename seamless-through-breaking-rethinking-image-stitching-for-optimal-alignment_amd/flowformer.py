@@ -101,6 +101,21 @@ class FlowFormer(ParamTree):
             d["kv"] = cat_lin([name + ".k", name + ".v"])
             return d
         pk["xin"] = attn_layer(c + "input_layer", False)
+        # first layer: the queries are the (normalised, projected) latent tokens themselves -- constants of the weights.
+        # Fold them through the key projection (scores against un-projected tokens; the key bias cancels in the softmax)
+        # and fold the value bias through the output projection (softmax weights sum to one).
+        with torch.no_grad():
+            L = pk["xin"]
+            lat = p[c + "latent_tokens"][0].double()
+            qn = torch.nn.functional.layer_norm(lat, (lat.shape[1],), L["n1"][0].double(), L["n1"][1].double(), 1e-5)
+            qv = qn @ L["q"][0].double().t() + L["q"][1].double()                        # [nl, 128]
+            Wk, Wv = L["kv"][0][:128].double(), L["kv"][0][128:].double()
+            bv = L["kv"][1][128:].double()
+            nl_, hd = qv.shape[0], 16
+            qp = torch.einsum("lhe,hec->lhc", qv.view(nl_, 8, hd), Wk.view(8, hd, 128)) * hd ** -0.5
+            L["qfold"] = qp.reshape(nl_ * 8, 128).float().contiguous()                   # row = latent*8 + head
+            L["wv_heads"] = Wv.float().contiguous()                                      # [8 heads x 16, 128]
+            L["proj_b_fold"] = (L["proj"][1].double() + L["proj"][0].double() @ bv).float().contiguous()
         pk["self"] = [attn_layer(c + f"encoder_layers.{i}", True) for i in range(HP["encoder_depth"])]
         vert = []
         for i in range(HP["encoder_depth"]):
@@ -252,17 +267,28 @@ class FlowFormer(ParamTree):
         lat = self._pk["latents"]
         nl = lat.shape[0]
         if first:
-            qn = _new(nl, 128, dev)
-            ops.layernorm(lat, L["n1"][0], L["n1"][1], qn, 1e-5)
-            q = _new(nl, 128, dev)
-            ops.conv_gemm(qn, L["q"][0], q, bias=L["q"][1])
-            kv = _new(M * P, 256, dev)
-            ops.conv_gemm(tokens, L["kv"][0], kv, bias=L["kv"][1])
             att = _new(M * nl, 128, dev)
-            ops.attention_small(q, (0, 128), kv[:, :128], (P * 256, 256), kv[:, 128:], (P * 256, 256), att, (nl * 128, 128),
-                                M, 8, nl, P, 16, 16 ** -0.5)
+            if nl == 8 and P % 2 == 0 and P <= 64:
+                # scores against the raw tokens with the folded queries, per-pixel softmax + token pooling, then the value
+                # projection per head on the pooled tokens: the [M*P, 256] K|V tensor is never built
+                S = _new(M * P, nl * 8, dev)
+                ops.conv_gemm(tokens, L["qfold"], S)
+                z = _new(M * nl * 8, 128, dev)
+                ops.latent_pool(S, tokens, z, M, P)
+                ops.conv_gemm(z.view(M * nl, 8 * 128)[:, :128], L["wv_heads"][:16], att[:, :16], batch=8, bsa=128, bsw=16 * 128, bsc=16)
+                proj_b = L["proj_b_fold"]
+            else:
+                qn = _new(nl, 128, dev)
+                ops.layernorm(lat, L["n1"][0], L["n1"][1], qn, 1e-5)
+                q = _new(nl, 128, dev)
+                ops.conv_gemm(qn, L["q"][0], q, bias=L["q"][1])
+                kv = _new(M * P, 256, dev)
+                ops.conv_gemm(tokens, L["kv"][0], kv, bias=L["kv"][1])
+                ops.attention_small(q, (0, 128), kv[:, :128], (P * 256, 256), kv[:, 128:], (P * 256, 256), att, (nl * 128, 128),
+                                    M, 8, nl, P, 16, 16 ** -0.5)
+                proj_b = L["proj"][1]
             x1 = _new(M * nl, 128, dev)
-            ops.conv_gemm(att, L["proj"][0], x1, bias=L["proj"][1], aux0=lat, row_mod=nl)
+            ops.conv_gemm(att, L["proj"][0], x1, bias=proj_b, aux0=lat, row_mod=nl)
         else:
             y = _new(M * nl, 128, dev)
             ops.layernorm(x, L["n1"][0], L["n1"][1], y, 1e-5)

@@ -171,6 +171,11 @@ def attention_small(q, qs, k, ks, v, vs, out, os_, B, heads, Nq, Nk, D, scale):
     return out
 
 
+def latent_pool(scores, tokens, z, pixels, P):
+    check(lib.st_latent_pool(_p(scores), _ld(scores), _p(tokens), _ld(tokens), _pc(z), pixels, P, _stream()), "st_latent_pool")
+    return z
+
+
 def attention_kvlds(q, qs, k, ks, v, vs, out, os_, B, heads, Nq, Nk, D, scale):
     check(lib.st_attention_kvlds(_p(q), qs[0], qs[1], _p(k), ks[0], ks[1], _p(v), vs[0], vs[1], _p(out), os_[0], os_[1],
                                  B, heads, Nq, Nk, D, scale, _stream()), "st_attention_kvlds")
