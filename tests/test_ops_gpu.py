@@ -618,3 +618,16 @@ def test_narrow_conv(ops):
     c = dev(coords)
     ops.conv_gemm(nhwc(x), pack_conv_w(w), c, geom=(B, H, W, 3, 3, 1, 1, 1, 1), bias=dev(b), epi="add", aux1=c)
     assert (c.cpu().double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("M,P", [(37, 64), (50, 4), (9, 30)])
+def test_latent_pool(ops, M, P):
+    """st_latent_pool: per pixel softmax over its P tokens for 64 score rows, then z = softmax(S)^T . T (fp64 torch check)."""
+    S = torch.randn(M * P, 64, generator=g(1)) * 3
+    T_ = torch.randn(M * P, 128, generator=g(2))
+    p = torch.softmax(S.double().view(M, P, 64), dim=1)                       # over tokens
+    ref = torch.einsum("mtr,mtc->mrc", p, T_.double().view(M, P, 128))       # [M, 64, 128]
+    Sw = torch.zeros(M * P, 72, device="cuda"); Sw[:, 4:68] = S.cuda()        # column slices of wider buffers
+    z = torch.empty(M * 64, 128, device="cuda")
+    ops.latent_pool(Sw[:, 4:68], dev(T_), z, M, P)
+    assert (z.cpu().double().view(M, 64, 128) - ref).abs().max() < 2e-5
