@@ -83,9 +83,10 @@ def corr_roofline(ops, B=8, N=4096, C=256, iters=10):
 def cpu_baseline():
     """CPU oracle (port of the reference path) on one 512x512 pair, all host cores."""
     from oracle import adapter as oadapter
-    from oracle import inputs, spec
+    from oracle import spec
+    from stitch_amd.data import structured_pair
     sd = spec.seeded_state_dict(1234)
-    a, b = inputs.structured_pair(512, 512, seed=7)
+    a, b = structured_pair(512, 512, seed=7)
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -123,12 +124,12 @@ def main():
                                 device_id=torch.device("cuda", local))
 
     import stitch_amd
-    from oracle import inputs                       # deterministic synthetic pairs (data only)
+    from stitch_amd.data import structured_pair     # deterministic synthetic pairs
     ops = stitch_amd.ops
     cfg, _ = stitch_amd.load_inference_config("all_img1_with_inpaint_g12_transRef")
     torch.manual_seed(1234)
     model = stitch_amd.build_model(cfg).cuda().eval()          # random-init weights of the architecture
-    pairs = [inputs.structured_pair(512, 512, seed=7 + rank + 100 * i) for i in range(max(1, args.batch))]
+    pairs = [structured_pair(512, 512, seed=7 + rank + 100 * i) for i in range(max(1, args.batch))]
     a, b = torch.cat([p[0] for p in pairs]).cuda(), torch.cat([p[1] for p in pairs]).cuda()
     nb = a.shape[0]
 

@@ -14,8 +14,8 @@ from .nets import W, flowformer, homo_offsets
 
 
 def _conj(H, M):
-    Minv = torch.inverse(M)
-    return torch.matmul(torch.matmul(Minv.expand_as(H), H), M.expand_as(H))
+    Minv = geom.inverse(M)
+    return geom.matmul3(geom.matmul3(Minv.expand_as(H), H), M.expand_as(H))
 
 
 def _scale_mat(w, h):
@@ -36,7 +36,7 @@ def forward_test_eval(sd, img1, img2, iters=12, stages=None):
     M = _scale_mat(w / 8, h / 8)
     ones = torch.ones_like(img2)
     output_H = geom.homo_transformer(torch.cat([img2, ones], 1), _conj(H, M), (h, w))   # :111
-    output_H_inv = geom.homo_transformer(torch.cat([img1, ones], 1), _conj(torch.inverse(H), M), (h, w))
+    output_H_inv = geom.homo_transformer(torch.cat([img1, ones], 1), _conj(geom.inverse(H), M), (h, w))
     warp2 = output_H[:, 0:3]
     flow_ij = flowformer(fw, img1, warp2, iters)[0]                                 # :167
     final = geom.warp(output_H, flow_ij)                                            # :170
@@ -77,12 +77,12 @@ def forward_test_out(sd, img1, img2, iters=12):
     ow, oh = int(wmax - wmin), int(hmax - hmin)                                      # :270-271
     M = _scale_mat(float(ow), float(oh))[0]                                          # :274-276
     N = _scale_mat(float(iw), float(ih))[0]
-    Ninv = torch.inverse(N)
+    Ninv = geom.inverse(N)
     I_ = torch.tensor([[1., 0., float(wmin)], [0., 1., float(hmin)], [0., 0., 1.]])
-    I_mat = torch.matmul(torch.matmul(Ninv, I_), M)[None]                            # :291
+    I_mat = geom.matmul3(geom.matmul3(Ninv, I_), M)[None]                            # :291
     homo1 = geom.homo_transformer(torch.cat([img1, torch.ones_like(img1)], 1), I_mat, (oh, ow))
-    Hc = torch.matmul(H, I_[None])                                                   # :306
-    H_mat = torch.matmul(torch.matmul(Ninv[None].expand(B, -1, -1), Hc), M[None].expand(B, -1, -1))
+    Hc = geom.matmul3(H, I_[None])                                                   # :306
+    H_mat = geom.matmul3(geom.matmul3(Ninv[None].expand(B, -1, -1), Hc), M[None].expand(B, -1, -1))
     homo2 = geom.homo_transformer(torch.cat([img2, torch.ones_like(img2)], 1), H_mat, (oh, ow))
     fmask = torch.ones_like(residual).mean(1, keepdim=True)
     rf = geom.homo_transformer(torch.cat([residual, fmask], 1), I_mat, (oh, ow))     # :314

@@ -153,3 +153,119 @@ void orc_morph_open(const float *m, float *out, int N, int H, int W, int ksz) {
     }
     free(bin); free(ero);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Small dense linear algebra exactly as the reference's torch-CPU calls evaluate it (measured bit for
+ * bit against torch 2.10 / oneMKL 2024.2 in the build container on thousands of matrices, see
+ * tests/test_oracle_pin.py::test_small_linalg_*):
+ *
+ *   torch.inverse(A)  (core/udis_utils/torch_DLT.py:42, core/flowHomoAdpater.py:105,112, core/warp_utils.py:24)
+ *     = linalg.solve(A, I): sgetrf of A^T (a C-contiguous A is handed to LAPACK as its transpose), then
+ *       sgetrs('T') against the identity: U^T y = e_c, L^T z = y, rows swapped back in reverse pivot order.
+ *       n = 8: right-looking LU, column scaled by the pivot's reciprocal, trailing update fmaf(-l, u, a);
+ *              both triangular solves are dot products over k whose 8 products (NOT fused) sit in
+ *              8 SIMD lanes (lane = k) and are reduced as ((l0+l4)+(l2+l6)) + ((l1+l5)+(l3+l7)); U's
+ *              diagonal is divided by.
+ *       n = 3: column 0 scaled by the reciprocal, column 1 divided; U's diagonal multiplied by its
+ *              reciprocal; y_i = (b_i - sum of unfused products) * r_i; x1 = fmaf(-l21, x2, y1);
+ *              x0 = y0 - fmaf(l10, x1, l20 * x2).
+ *   torch.matmul of small batched matrices ([8x8]@[8x1] torch_DLT.py:43, [3x3]@[3x3]
+ *   flowHomoAdpater.py:108,112,226,291,306-307): contraction*rows*cols < 400 takes ATen's plain
+ *   baddbmm loop: acc = 0; acc += a[i][k]*b[k][j] for ascending k, products not fused.
+ * ---------------------------------------------------------------------------------------------- */
+static float lanes8_sum(const float *l) {
+    float a0 = l[0] + l[4], a1 = l[1] + l[5], a2 = l[2] + l[6], a3 = l[3] + l[7];
+    float b0 = a0 + a2, b1 = a1 + a3;
+    return b0 + b1;
+}
+
+/* torch.inverse of a row-major 8x8 */
+void orc_inv8(const float *Ain, float *out) {
+    enum { n = 8 };
+    float A[n][n], B[n][n];
+    int piv[n];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[i][j] = Ain[j * n + i];
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        float best = fabsf(A[k][k]);
+        for (int i = k + 1; i < n; ++i) if (fabsf(A[i][k]) > best) { best = fabsf(A[i][k]); p = i; }
+        piv[k] = p;
+        if (p != k) for (int j = 0; j < n; ++j) { float t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
+        float r = 1.0f / A[k][k];
+        for (int i = k + 1; i < n; ++i) A[i][k] = A[i][k] * r;
+        for (int i = k + 1; i < n; ++i) for (int j = k + 1; j < n; ++j) A[i][j] = fmaf(-A[i][k], A[k][j], A[i][j]);
+    }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) B[i][j] = (i == j) ? 1.0f : 0.0f;
+    for (int c = 0; c < n; ++c) {
+        for (int i = 0; i < n; ++i) {
+            float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < i; ++k) l[k] = A[k][i] * B[k][c];
+            B[i][c] = (B[i][c] - lanes8_sum(l)) / A[i][i];
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = i + 1; k < n; ++k) l[k] = A[k][i] * B[k][c];
+            B[i][c] = B[i][c] - lanes8_sum(l);
+        }
+    }
+    for (int k = n - 1; k >= 0; --k)
+        if (piv[k] != k) for (int j = 0; j < n; ++j) { float t = B[k][j]; B[k][j] = B[piv[k]][j]; B[piv[k]][j] = t; }
+    memcpy(out, B, sizeof(B));
+}
+
+/* torch.inverse of a row-major 3x3 */
+void orc_inv3(const float *Ain, float *out) {
+    float A[3][3], B[3][3];
+    int piv[3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = Ain[j * 3 + i];
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        float best = fabsf(A[k][k]);
+        for (int i = k + 1; i < 3; ++i) if (fabsf(A[i][k]) > best) { best = fabsf(A[i][k]); p = i; }
+        piv[k] = p;
+        if (p != k) for (int j = 0; j < 3; ++j) { float t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
+        if (k == 0) { float r = 1.0f / A[0][0]; A[1][0] = A[1][0] * r; A[2][0] = A[2][0] * r; }
+        else if (k == 1) A[2][1] = A[2][1] / A[1][1];
+        for (int i = k + 1; i < 3; ++i) for (int j = k + 1; j < 3; ++j) A[i][j] = fmaf(-A[i][k], A[k][j], A[i][j]);
+    }
+    float r0 = 1.0f / A[0][0], r1 = 1.0f / A[1][1], r2 = 1.0f / A[2][2];
+    for (int c = 0; c < 3; ++c) {
+        float b0 = (c == 0), b1 = (c == 1), b2 = (c == 2);
+        float y0 = b0 * r0;
+        float y1 = (b1 - A[0][1] * y0) * r1;
+        float y2 = (b2 - (A[0][2] * y0 + A[1][2] * y1)) * r2;
+        float x2 = y2;
+        float x1 = fmaf(-A[2][1], x2, y1);
+        float x0 = y0 - fmaf(A[1][0], x1, A[2][0] * x2);
+        B[0][c] = x0; B[1][c] = x1; B[2][c] = x2;
+    }
+    for (int k = 2; k >= 0; --k)
+        if (piv[k] != k) for (int j = 0; j < 3; ++j) { float t = B[k][j]; B[k][j] = B[piv[k]][j]; B[piv[k]][j] = t; }
+    memcpy(out, B, sizeof(B));
+}
+
+/* small torch.matmul: [n x m] @ [m x p], plain ascending-k accumulation from zero */
+void orc_matmul_small(const float *A, const float *Bm, float *out, int n, int m, int p) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < p; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < m; ++k) acc = acc + A[i * m + k] * Bm[k * p + j];
+            out[i * p + j] = acc;
+        }
+}
+
+/* tensor_DLT (core/udis_utils/torch_DLT.py:17-45): src, dst [4][2] -> H [9] (H[8] = 1).
+ * Rows (x y 1 0 0 0 -u*x -u*y), (0 0 0 x y 1 -v*x -v*y); rhs = (u, v) interleaved; h = inverse(A) @ b. */
+void orc_dlt4(const float *src, const float *dst, float *H) {
+    float A[64], Ainv[64], b[8];
+    for (int p = 0; p < 4; ++p) {
+        float x = src[2 * p], y = src[2 * p + 1], u = dst[2 * p], v = dst[2 * p + 1];
+        float *r0 = A + 16 * p, *r1 = r0 + 8;
+        r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -(u * x); r0[7] = -(u * y);
+        r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -(v * x); r1[7] = -(v * y);
+        b[2 * p] = u; b[2 * p + 1] = v;
+    }
+    orc_inv8(A, Ainv);
+    orc_matmul_small(Ainv, b, H, 8, 8, 1);
+    H[8] = 1.0f;
+}

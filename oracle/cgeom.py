@@ -53,3 +53,33 @@ def morph_open(mask, ksz=19):
     out = np.empty_like(mask)
     lib().orc_morph_open(_p(mask), _p(out), B * Cc, H, W, ksz)
     return out
+
+
+def inverse(A):
+    """torch.inverse of [B,3,3] or [B,8,8] fp32 in the reference's (MKL) operation order."""
+    A = np.ascontiguousarray(A, np.float32)
+    n = A.shape[-1]
+    out = np.empty_like(A)
+    fn = {3: lib().orc_inv3, 8: lib().orc_inv8}[n]
+    for a, o in zip(A.reshape(-1, n, n), out.reshape(-1, n, n)):
+        fn(_p(a), _p(o))
+    return out
+
+
+def matmul_small(A, Bm):
+    A, Bm = np.ascontiguousarray(A, np.float32), np.ascontiguousarray(Bm, np.float32)
+    n, m = A.shape[-2:]
+    p = Bm.shape[-1]
+    out = np.empty(A.shape[:-2] + (n, p), np.float32)
+    for a, b, o in zip(A.reshape(-1, n, m), Bm.reshape(-1, m, p), out.reshape(-1, n, p)):
+        lib().orc_matmul_small(_p(a), _p(b), _p(o), n, m, p)
+    return out
+
+
+def dlt4(src, dst):
+    """tensor_DLT: src, dst [B,4,2] -> H [B,3,3]."""
+    src, dst = np.ascontiguousarray(src, np.float32), np.ascontiguousarray(dst, np.float32)
+    H = np.empty((src.shape[0], 9), np.float32)
+    for s, d, h in zip(src, dst, H):
+        lib().orc_dlt4(_p(s), _p(d), _p(h))
+    return H.reshape(-1, 3, 3)

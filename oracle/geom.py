@@ -15,9 +15,16 @@ from . import cgeom
 def dlt4(src, dst):
     """4-point DLT, ``h = A^-1 b`` (reference: core/udis_utils/torch_DLT.py:17-45).
 
-    src, dst: [B,4,2] -> H [B,3,3] with H[2,2]=1.  Row 2i = [x y 1 0 0 0 -x*u -y*u], row 2i+1 =
-    [0 0 0 x y 1 -x*v -y*v]; rhs = (u, v) interleaved.
+    src, dst: [B,4,2] -> H [B,3,3] with H[2,2]=1.  Evaluated by the plain-C restatement (``orc_dlt4``): the
+    reference's ``torch.inverse`` + ``torch.matmul`` in the exact operation order of its torch-CPU / MKL
+    build (bit-identical to the reference golden ``dlt_H``), so the oracle does not depend on which MKL
+    code path the host CPU selects.  ``dlt4_torch`` is the same computation through torch itself.
     """
+    return torch.from_numpy(cgeom.dlt4(src.detach().numpy(), dst.detach().numpy()))
+
+
+def dlt4_torch(src, dst):
+    """tensor_DLT through torch's own inverse/matmul (used to pin ``orc_dlt4`` in the build container)."""
     B = src.shape[0]
     x, y = src[..., 0], src[..., 1]
     u, v = dst[..., 0], dst[..., 1]
@@ -28,6 +35,17 @@ def dlt4(src, dst):
     b = dst.reshape(B, 8, 1)
     h8 = torch.matmul(torch.inverse(A), b).reshape(B, 8)
     return torch.cat([h8, torch.ones(B, 1, dtype=h8.dtype)], 1).reshape(B, 3, 3)
+
+
+def inverse(A):
+    """``torch.inverse`` of [.., 3, 3] / [.., 8, 8] fp32 in the reference's operation order (``orc_inv3/8``)."""
+    return torch.from_numpy(cgeom.inverse(A.detach().numpy()))
+
+
+def matmul3(A, B):
+    """small ``torch.matmul`` ([..,3,3]@[..,3,3]) in the reference's operation order (``orc_matmul_small``)."""
+    A, B = torch.broadcast_tensors(A, B)
+    return torch.from_numpy(cgeom.matmul_small(A.contiguous().numpy(), B.contiguous().numpy()))
 
 
 def homo_transformer(U, theta, out_hw, return_idx=False):
@@ -49,7 +67,7 @@ def rigid_mesh(batch, height, width, grid_h=511, grid_w=511):
 def h2mesh(H, mesh):
     """reference: core/warp_utils.py:20-34: mesh points through H^-1 with perspective divide."""
     B, gh, gw, _ = mesh.shape
-    Hinv = torch.inverse(H)
+    Hinv = inverse(H)
     pts = torch.cat([mesh.reshape(B, -1, 2), torch.ones(B, gh * gw, 1)], 2)
     tar = torch.matmul(Hinv, pts.permute(0, 2, 1))
     mx = tar[:, 0] / tar[:, 2]

@@ -127,7 +127,7 @@ def sine_pe(x, dim, norm=1 / 200):
 
 def coords_grid(B, H, W):
     ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
-    return torch.stack([xs, ys], 0).float()[None].repeat(B, 1, 1, 1)
+    return torch.stack([xs, ys], 0).to(torch.get_default_dtype())[None].repeat(B, 1, 1, 1)
 
 
 def mha(q, k, v, heads, scale):

@@ -1,7 +1,7 @@
 """Inference + save harness of the stitching path (re-statement of the reference's out.py:15-54,106-146,158-275,
 SURVEY.md section 8 f-1) on the MI355X package.
 
-    python out.py --data_root_path ./demo/ --inf_cfg all_img1_with_inpaint_g12_transRef [--restore_ckpt CKPT]
+    python out.py --data_root_path ./demo/ --inf_cfg all_img1_with_inpaint_g12_transRef [--ckpt_path CKPT]
 
 Same flags, `demo.txt` pair list (one directory per line holding input1.jpg / input2.jpg), RGB-float loading and
 result-directory naming as the reference.  The forward (`type="test_out"`) runs on the HIP kernels; its images are
@@ -25,7 +25,8 @@ def get_config(argv=None):
     p.add_argument("--data_root_path", type=str, default="./demo/")
     p.add_argument("--txt_file", type=str, default="demo.txt")
     p.add_argument("--result_dir", type=str, default="results")
-    p.add_argument("--restore_ckpt", type=str, default="")
+    p.add_argument("--ckpt_path", "--restore_ckpt", dest="restore_ckpt", type=str, default="",
+                   help="checkpoint (reference flag: --ckpt_path, out.py:18; --restore_ckpt kept as an alias); empty = random init")
     p.add_argument("--model_config_name", type=str, default="last_config")
     p.add_argument("--inf_cfg", type=str, default="all_img1_with_inpaint_g12_transRef")
     p.add_argument("--gpu", type=int, default=0)

@@ -56,9 +56,16 @@ class FlowHomoAdpater(nn.Module):
         """M = [[w/2,0,w/2],[0,h/2,h/2],[0,0,1]] and its inverse (flowHomoAdpater.py:98-107)."""
         k = ("scale", float(w), float(h), str(dev))
         if k not in self._host:
-            M = torch.tensor([[w / 2.0, 0., w / 2.0], [0., h / 2.0, h / 2.0], [0., 0., 1.]], dtype=torch.float32)
-            self._host[k] = (M.to(dev), torch.inverse(M).contiguous().to(dev))
+            M = torch.tensor([[w / 2.0, 0., w / 2.0], [0., h / 2.0, h / 2.0], [0., 0., 1.]], dtype=torch.float32).to(dev)
+            self._host[k] = (M, self._inv3(M))
         return self._host[k]
+
+    def _inv3(self, M):
+        """torch.inverse of a 3x3 in the reference's arithmetic, on the device: eye @ inverse(M) @ eye is exact."""
+        eye = self._mat(M.device, "eye", [[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]])
+        out = torch.empty((1, 3, 3), device=M.device)
+        ops.mat3_sandwich(eye, M.reshape(1, 3, 3).contiguous(), eye, out, invert=True)
+        return out[0]
 
     def _corners(self, dev, w, h):
         return self._mat(dev, ("corners", float(w), float(h)), [[0., 0.], [w, 0.], [0., h], [w, h]])
@@ -88,8 +95,15 @@ class FlowHomoAdpater(nn.Module):
             if type == "test_out":
                 return self.test_out_forward(input1_tensor, input2_tensor, pad_mode=pad_mode,
                                              preprocess_callback=preprocess_callback)
-            if type == "train" or type == "test_eval":
+            if type == "test_eval":
+                if self.training:
+                    raise NotImplementedError("inference-only drop-in: call .eval() first (the training branch of "
+                                              "train_eval_foward, flowHomoAdpater.py:83-191, is not implemented)")
                 return self.train_eval_foward(input1_tensor, input2_tensor)
+            if type == "train":
+                # the reference returns every refinement prediction with gradients here; this path is no_grad with
+                # frozen parameters, so training through it would silently learn nothing
+                raise NotImplementedError("type='train' is not supported by the gfx950 inference path")
             raise NotImplementedError
 
     def graphed(self, type="test_eval"):
@@ -112,7 +126,7 @@ class FlowHomoAdpater(nn.Module):
         output_H = ops.homo_warp(input2_tensor, H_mat.view(B, 9), (img_h, img_w), n_ones=3)            # :111
         output_H_inv = ops.homo_warp(input1_tensor, H_inv_mat.view(B, 9), (img_h, img_w), n_ones=3)    # :113
         warp2 = output_H[:, 0:3].contiguous()
-        fb = _flag(self.cfg, "use_fb_consistency_mask", True)
+        fb = _flag(self.cfg, "use_fb_consistency_mask")              # missing key = False, as hasattr(...) and ... (:176)
         if fb:
             flow_ij, flow_ji = self.predict_flow_pair(input1_tensor, warp2)                            # :167 and :178, one batch
         else:
@@ -124,7 +138,7 @@ class FlowHomoAdpater(nn.Module):
         else:
             occ = torch.ones((B, 1, img_h, img_w), device=dev)
         overlap = ops.eval_finish(final, occ)                                                          # :171-174,182
-        if _flag(self.cfg, "use_fb_consistency_mask", True):
+        if fb:
             out.update(origin_occlusion_mask=occ.squeeze(1))
         out.update(output_H=output_H, output_H_inv=output_H_inv, final_warp_output=final, overlap=overlap,
                    flow_predictions=[flow_ij], H=H)
@@ -134,8 +148,9 @@ class FlowHomoAdpater(nn.Module):
     def test_out_forward(self, input1_tensor, input2_tensor, pad_mode="constant", preprocess_callback=None):
         if self.use_forward:
             raise NotImplementedError
-        if not _flag(self.cfg, "test_not_use_combine_h_flow", True) or _flag(self.cfg, "use_whole_resolution"):
-            raise NotImplementedError
+        if not _flag(self.cfg, "test_not_use_combine_h_flow") or _flag(self.cfg, "use_whole_resolution"):
+            raise NotImplementedError("only the shipped branch (test_not_use_combine_h_flow=True, use_whole_resolution=False, "
+                                      "flowHomoAdpater.py:303-360) is implemented")
         dev = input1_tensor.device
         B, _, img_h, img_w = input1_tensor.shape
         if B != 1:
@@ -161,23 +176,23 @@ class FlowHomoAdpater(nn.Module):
         width_max, width_min = int(max(float(img_w), mxx)), int(min(0.0, mnx))                         # .int() truncation
         height_max, height_min = int(max(float(img_h), mxy)), int(min(0.0, mny))
         out_width, out_height = width_max - width_min, height_max - height_min                         # :270-271
-        Mt = torch.tensor([[out_width / 2.0, 0., out_width / 2.0], [0., out_height / 2.0, out_height / 2.0], [0., 0., 1.]])
-        Nt = torch.tensor([[img_w / 2.0, 0., img_w / 2.0], [0., img_h / 2.0, img_h / 2.0], [0., 0., 1.]])
-        Ninv = torch.inverse(Nt).contiguous()
-        I_ = torch.tensor([[1., 0., float(width_min)], [0., 1., float(height_min)], [0., 0., 1.]])
-        I_mat = torch.matmul(torch.matmul(Ninv, I_), Mt).unsqueeze(0).contiguous().to(dev)                          # :291 (3x3 host constants)
+        Mt = torch.tensor([[out_width / 2.0, 0., out_width / 2.0], [0., out_height / 2.0, out_height / 2.0], [0., 0., 1.]]).to(dev)
+        _, Ninv = self._scale_pair(dev, float(img_w), float(img_h))                                   # :274-276
+        I_ = torch.tensor([[1., 0., float(width_min)], [0., 1., float(height_min)], [0., 0., 1.]]).to(dev)
+        I_mat = torch.empty((1, 3, 3), device=dev)
+        ops.mat3_sandwich(Ninv, I_.view(1, 3, 3), Mt, I_mat)                                          # :291
         canvas = (out_height, out_width)
         homo_output = ops.homo_warp(input1_tensor, I_mat.view(1, 9), canvas, n_ones=3)                 # :292
         ident = self._mat(dev, "eye", [[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]])
         Hc = torch.empty_like(H)
-        ops.mat3_sandwich(ident, H, I_.to(dev), Hc)                                                    # H @ I_  (:306)
+        ops.mat3_sandwich(ident, H, I_, Hc)                                                    # H @ I_  (:306)
         H_mat = torch.empty_like(H)
-        ops.mat3_sandwich(Ninv.to(dev), Hc, Mt.to(dev), H_mat)                                         # :307
+        ops.mat3_sandwich(Ninv, Hc, Mt, H_mat)                                         # :307
         homo_output2 = ops.homo_warp(input2_tensor, H_mat.view(B, 9), canvas, n_ones=3)                # :310
         rf = ops.homo_warp(residual, I_mat.view(1, 9), canvas, n_ones=1)                               # :313-314
         final = ops.flow_warp(homo_output2, rf[:, 0:2].contiguous(), rf[:, 2:3].contiguous())          # :316-317
-        if not _flag(self.cfg, "use_fb_consistency_mask", True):
-            raise NotImplementedError("shipped inference config sets use_fb_consistency_mask=True")
+        if not _flag(self.cfg, "use_fb_consistency_mask"):
+            raise NotImplementedError("shipped inference config sets use_fb_consistency_mask=True (flowHomoAdpater.py:324)")
         back = ops.resize_bilinear(back512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))
         occ = ops.occlusion_from_range(ops.range_map(back), False)                                     # :332
         origin_occ = ops.morph_open(occ, 19)                                                           # :333-334
@@ -202,7 +217,7 @@ class GraphedForward:
     """
 
     def __init__(self, model, type="test_eval"):
-        if type not in ("test_eval", "train"):
+        if type != "test_eval":
             raise NotImplementedError("only the fixed-shape test_eval path can be captured")
         self.model, self.type = model, type
         self._graphs = {}

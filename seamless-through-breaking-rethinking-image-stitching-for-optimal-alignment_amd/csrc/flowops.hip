@@ -52,6 +52,11 @@ extern "C" int st_flow_from_coords(const float* coords1, float* flow4, int32_t l
 // (RAFT quirk), channel = i*(2r+1) + j.  grid_sample(bilinear, zeros, align_corners=True).
 __global__ __launch_bounds__(256) void cost_lookup_kernel(const float* __restrict__ maps, const float* __restrict__ coords,
                                                           float* __restrict__ out, int ldo, int Nq, int H2, int W2, int r) {
+    // every rounding of the reference's coordinate round trip (normalise in bilinear_sampler, un-normalise in
+    // grid_sample) and of the four weights is kept: with contraction the weights would come from the unrounded
+    // product ix = a*(W-1) while floor() sees the rounded one, a ~2e-6 px inconsistency that the cost volume's
+    // ~1e3-per-pixel gradients turn into 5e-3 errors of the looked-up costs (profiles/r2_parity_trace_*.txt)
+#pragma clang fp contract(off)
     const int side = 2 * r + 1, nch = side * side;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)Nq * nch) return;
@@ -71,11 +76,11 @@ __global__ __launch_bounds__(256) void cost_lookup_kernel(const float* __restric
     const float* m = maps + n * (size_t)(H2 * W2);
     const bool xin0 = x0 >= 0 && x0 < W2, xin1 = x1 >= 0 && x1 < W2;
     const bool yin0 = y0 >= 0 && y0 < H2, yin1 = y1 >= 0 && y1 < H2;
-    float v = 0.f;
-    if (xin0 && yin0) v += m[y0 * W2 + x0] * nw;
-    if (xin1 && yin0) v += m[y0 * W2 + x1] * ne;
-    if (xin0 && yin1) v += m[y1 * W2 + x0] * sw;
-    if (xin1 && yin1) v += m[y1 * W2 + x1] * se;
+    // ATen CPU grid_sample: one product, then three fused multiply-adds (out-of-range taps contribute 0)
+    float v = (xin0 && yin0 ? m[y0 * W2 + x0] : 0.f) * nw;
+    v = __fmaf_rn(xin1 && yin0 ? m[y0 * W2 + x1] : 0.f, ne, v);
+    v = __fmaf_rn(xin0 && yin1 ? m[y1 * W2 + x0] : 0.f, sw, v);
+    v = __fmaf_rn(xin1 && yin1 ? m[y1 * W2 + x1] : 0.f, se, v);
     out[n * ldo + ch] = v;
 }
 

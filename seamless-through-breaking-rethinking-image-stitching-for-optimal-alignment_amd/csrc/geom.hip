@@ -95,25 +95,72 @@ extern "C" int st_homo_warp(const float* U, const float* theta, float* out, int3
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3x3 helpers (tiny; one thread per batch element).  matmul rows follow the sequential fma chain.
+// 3x3 helpers (tiny; one thread per batch element).  The reference evaluates these with torch-CPU calls whose
+// operation order is restated in oracle/c/geom_oracle.c (orc_inv3 / orc_inv8 / orc_matmul_small, pinned bit for
+// bit to the reference golden); this file is compiled with -ffp-contract=off, so a*b+c below is two roundings and
+// only __fmaf_rn is fused.
+// small torch.matmul (flowHomoAdpater.py:108,112,226,291,306-307): acc = 0; acc += a*b for ascending k, unfused.
 __device__ __forceinline__ void mat3_mul(const float* A, const float* Bm, float* o) {
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) {
             float acc = A[r * 3] * Bm[c];
-            acc = __fmaf_rn(A[r * 3 + 1], Bm[3 + c], acc);
-            acc = __fmaf_rn(A[r * 3 + 2], Bm[6 + c], acc);
+            acc = acc + A[r * 3 + 1] * Bm[3 + c];
+            acc = acc + A[r * 3 + 2] * Bm[6 + c];
             o[r * 3 + c] = acc;
         }
 }
-__device__ __forceinline__ void mat3_inv(const float* A, float* o) {
-    const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5], g = A[6], h = A[7], i = A[8];
-    const double c00 = e * i - f * h, c01 = c * h - b * i, c02 = b * f - c * e;
-    const double c10 = f * g - d * i, c11 = a * i - c * g, c12 = c * d - a * f;
-    const double c20 = d * h - e * g, c21 = b * g - a * h, c22 = a * e - b * d;
-    const double det = a * c00 + b * c10 + c * c20;
-    o[0] = (float)(c00 / det); o[1] = (float)(c01 / det); o[2] = (float)(c02 / det);
-    o[3] = (float)(c10 / det); o[4] = (float)(c11 / det); o[5] = (float)(c12 / det);
-    o[6] = (float)(c20 / det); o[7] = (float)(c21 / det); o[8] = (float)(c22 / det);
+// torch.inverse of a 3x3 (flowHomoAdpater.py:112, warp_utils.py:24) = sgetrf(A^T) + sgetrs('T', I) in MKL's order:
+// column 0 scaled by the pivot's reciprocal, column 1 divided, fused trailing updates; U's diagonal by reciprocal.
+__device__ __forceinline__ void mat3_inv(const float* Ain, float* o) {
+    float A[3][3], Bm[3][3];
+    int piv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) A[i][j] = Ain[j * 3 + i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        float best = fabsf(A[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < 3; ++i) if (fabsf(A[i][k]) > best) { best = fabsf(A[i][k]); p = i; }
+        piv[k] = p;
+#pragma unroll
+        for (int q = 1; q < 3; ++q)
+            if (q > k && p == q) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { const float t = A[k][j]; A[k][j] = A[q][j]; A[q][j] = t; }
+            }
+        if (k == 0) { const float r = 1.0f / A[0][0]; A[1][0] = A[1][0] * r; A[2][0] = A[2][0] * r; }
+        else if (k == 1) A[2][1] = A[2][1] / A[1][1];
+#pragma unroll
+        for (int i = k + 1; i < 3; ++i)
+#pragma unroll
+            for (int j = k + 1; j < 3; ++j) A[i][j] = __fmaf_rn(-A[i][k], A[k][j], A[i][j]);
+    }
+    const float r0 = 1.0f / A[0][0], r1 = 1.0f / A[1][1], r2 = 1.0f / A[2][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float b0 = (c == 0) ? 1.f : 0.f, b1 = (c == 1) ? 1.f : 0.f, b2 = (c == 2) ? 1.f : 0.f;
+        const float y0 = b0 * r0;
+        const float y1 = (b1 - A[0][1] * y0) * r1;
+        const float y2 = (b2 - (A[0][2] * y0 + A[1][2] * y1)) * r2;
+        const float x1 = __fmaf_rn(-A[2][1], y2, y1);
+        const float x0 = y0 - __fmaf_rn(A[1][0], x1, A[2][0] * y2);
+        Bm[0][c] = x0; Bm[1][c] = x1; Bm[2][c] = y2;
+    }
+#pragma unroll
+    for (int k = 2; k >= 0; --k)
+#pragma unroll
+        for (int q = 1; q < 3; ++q)
+            if (q > k && piv[k] == q) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { const float t = Bm[k][j]; Bm[k][j] = Bm[q][j]; Bm[q][j] = t; }
+            }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[i * 3 + j] = Bm[i][j];
 }
 
 // out[b] = L @ (invert ? inv(X[b]) : X[b]) @ R   with L, R shared 3x3 (flowHomoAdpater.py:108,112,226,307)
@@ -139,36 +186,61 @@ extern "C" int st_mat3_sandwich(const float* L, const float* X, const float* R, 
 
 // ---------------------------------------------------------------------------------------------
 // 4-point DLT (core/udis_utils/torch_DLT.py:17-45): src/dst [B,4,2] (+ optional motion added to
-// dst and a common divisor, flowHomoAdpater.py:95-96) -> H [B,3,3].  8x8 solve, fp64 partial pivoting.
+// dst and a common divisor, flowHomoAdpater.py:95-96) -> H [B,3,3].  h = inverse(A) @ b in fp32, in the operation
+// order of the reference's torch-CPU evaluation (oracle/c/geom_oracle.c: orc_inv8 / orc_dlt4, bit-identical to the
+// reference golden): LU of A^T with partial pivoting (reciprocal column scaling, fused trailing update),
+// sgetrs('T') against the identity with 8-lane tree-reduced unfused dot products, plain ascending-k mat-vec.
+__device__ __forceinline__ float lanes8_sum(const float* l) {
+    const float a0 = l[0] + l[4], a1 = l[1] + l[5], a2 = l[2] + l[6], a3 = l[3] + l[7];
+    const float b0 = a0 + a2, b1 = a1 + a3;
+    return b0 + b1;
+}
 __global__ void dlt4_kernel(const float* __restrict__ src, const float* __restrict__ motion, float* __restrict__ Hout, int B,
                             float mscale_x, float mscale_y, float div) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double A[8][9];
+    float A[8][8], X[8][8], rhs[8];             // A holds the TRANSPOSE of the DLT matrix: A[col][row]
+    int piv[8];
     for (int p = 0; p < 4; ++p) {
         const float sx = src[p * 2], sy = src[p * 2 + 1];
         float dx = sx, dy = sy;
         if (motion) { dx = sx + motion[(b * 4 + p) * 2] * mscale_x; dy = sy + motion[(b * 4 + p) * 2 + 1] * mscale_y; }
         const float x = sx / div, y = sy / div, u = dx / div, v = dy / div;
-        const float ux = u * x, uy = u * y, vx = v * x, vy = v * y;   // M2 entries are fp32 products (torch_DLT.py:30-33)
-        double* r0 = A[2 * p];
-        double* r1 = A[2 * p + 1];
-        r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -ux; r0[7] = -uy; r0[8] = u;
-        r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -vx; r1[7] = -vy; r1[8] = v;
+        const float r0[8] = {x, y, 1.f, 0.f, 0.f, 0.f, -(u * x), -(u * y)};
+        const float r1[8] = {0.f, 0.f, 0.f, x, y, 1.f, -(v * x), -(v * y)};
+        for (int j = 0; j < 8; ++j) { A[j][2 * p] = r0[j]; A[j][2 * p + 1] = r1[j]; }
+        rhs[2 * p] = u; rhs[2 * p + 1] = v;
+    }
+    for (int k = 0; k < 8; ++k) {
+        int p = k;
+        float best = fabsf(A[k][k]);
+        for (int i = k + 1; i < 8; ++i) if (fabsf(A[i][k]) > best) { best = fabsf(A[i][k]); p = i; }
+        piv[k] = p;
+        if (p != k) for (int j = 0; j < 8; ++j) { const float t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
+        const float r = 1.0f / A[k][k];
+        for (int i = k + 1; i < 8; ++i) A[i][k] = A[i][k] * r;
+        for (int i = k + 1; i < 8; ++i)
+            for (int j = k + 1; j < 8; ++j) A[i][j] = __fmaf_rn(-A[i][k], A[k][j], A[i][j]);
     }
     for (int c = 0; c < 8; ++c) {
-        int piv = c;
-        double best = fabs(A[c][c]);
-        for (int r = c + 1; r < 8; ++r) if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
-        if (piv != c) for (int k = 0; k < 9; ++k) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
-        const double inv = 1.0 / A[c][c];
-        for (int r = 0; r < 8; ++r) {
-            if (r == c) continue;
-            const double f = A[r][c] * inv;
-            for (int k = c; k < 9; ++k) A[r][k] -= f * A[c][k];
+        for (int i = 0; i < 8; ++i) {           // U^T y = e_c
+            float l[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < i; ++k) l[k] = A[k][i] * X[k][c];
+            X[i][c] = ((i == c ? 1.f : 0.f) - lanes8_sum(l)) / A[i][i];
+        }
+        for (int i = 7; i >= 0; --i) {          // L^T z = y
+            float l[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int k = i + 1; k < 8; ++k) l[k] = A[k][i] * X[k][c];
+            X[i][c] = X[i][c] - lanes8_sum(l);
         }
     }
-    for (int k = 0; k < 8; ++k) Hout[9 * b + k] = (float)(A[k][8] / A[k][k]);
+    for (int k = 7; k >= 0; --k)
+        if (piv[k] != k) for (int j = 0; j < 8; ++j) { const float t = X[k][j]; X[k][j] = X[piv[k]][j]; X[piv[k]][j] = t; }
+    for (int i = 0; i < 8; ++i) {
+        float acc = 0.f;
+        for (int k = 0; k < 8; ++k) acc = acc + X[i][k] * rhs[k];
+        Hout[9 * b + i] = acc;
+    }
     Hout[9 * b + 8] = 1.0f;
 }
 
@@ -252,11 +324,12 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(const float* __restrict_
     const float m = mul ? mul[(size_t)b * hw + pix] : 1.0f;
     for (int c = 0; c < C; ++c) {
         const float* im = x + ((size_t)b * C + c) * hw;
-        float v = 0.f;
-        if (xin0 && yin0) v = v + im[(size_t)y0 * W + x0] * nw;
-        if (xin1 && yin0) v = v + im[(size_t)y0 * W + x1] * ne;
-        if (xin0 && yin1) v = v + im[(size_t)y1 * W + x0] * sw;
-        if (xin1 && yin1) v = v + im[(size_t)y1 * W + x1] * se;
+        // ATen's CPU grid_sample accumulates nw*v + ne*v + sw*v + se*v as one product followed by three fused
+        // multiply-adds (measured bit for bit), out-of-range taps contributing 0
+        float v = (xin0 && yin0 ? im[(size_t)y0 * W + x0] : 0.f) * nw;
+        v = __fmaf_rn(xin1 && yin0 ? im[(size_t)y0 * W + x1] : 0.f, ne, v);
+        v = __fmaf_rn(xin0 && yin1 ? im[(size_t)y1 * W + x0] : 0.f, sw, v);
+        v = __fmaf_rn(xin1 && yin1 ? im[(size_t)y1 * W + x1] : 0.f, se, v);
         out[((size_t)b * C + c) * hw + pix] = mul ? v * m : v;
     }
 }

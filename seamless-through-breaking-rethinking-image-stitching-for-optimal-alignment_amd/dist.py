@@ -26,12 +26,18 @@ def shard_indices(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
-def gather_metrics(local_idx, local_vals, n_pairs, device=None):
+def gather_metrics(local_idx, local_vals, n_pairs, device=None, k=None):
     """All ranks contribute (index, values[k]) rows; every rank returns the full [n_pairs, k] table.
 
-    The only collective of the path (~16 B per pair): one all_gather of fixed-size padded blocks."""
-    vals = torch.as_tensor(local_vals, dtype=torch.float64).reshape(len(local_idx), -1)
-    k = vals.shape[1] if vals.numel() else 1
+    The only collective of the path (~16 B per pair): one all_gather of fixed-size padded blocks.  ``k`` (values
+    per pair) must be passed whenever a rank can own zero pairs (n_pairs < world): an empty shard cannot infer it,
+    and every rank has to reach the all_gather with the same block shape."""
+    vals = torch.as_tensor(local_vals, dtype=torch.float64)
+    if k is None:
+        if len(local_idx) == 0:
+            raise ValueError("gather_metrics: pass k= (values per pair) when the local shard may be empty")
+        k = vals.reshape(len(local_idx), -1).shape[1]
+    vals = vals.reshape(len(local_idx), k)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         out = torch.full((n_pairs, k), float("nan"), dtype=torch.float64)
         if len(local_idx):

@@ -73,5 +73,5 @@ def validate_with_model(model, val_dataset, batch_size=1, device=None, verbose=F
             if verbose:
                 for (p, s) in m.tolist():
                     print(f"rank {rank}: psnr = {p:.6f} ssim = {s:.6f}")
-    table = sdist.gather_metrics(mine, vals if vals else torch.zeros((0, 2)), n)
+    table = sdist.gather_metrics(mine, vals if vals else torch.zeros((0, 2)), n, k=2)
     return summarize(table[:, 0].tolist(), table[:, 1].tolist()), table

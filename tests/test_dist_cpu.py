@@ -19,6 +19,10 @@ WORKER = textwrap.dedent("""
     assert table.shape == (n, 2)
     assert torch.equal(table[:, 0], torch.arange(n, dtype=torch.float64) * 2.0)
     assert torch.equal(table[:, 1], torch.arange(n, dtype=torch.float64) + 0.5)
+    # a short list: n_pairs < world leaves rank 1 with an empty shard; it must still reach the all_gather
+    idx1 = sd.shard_indices(1, rank, world)
+    t1 = sd.gather_metrics(idx1, [[7.0, 8.0]] if idx1 else torch.zeros((0, 2)), 1, k=2)
+    assert t1.shape == (1, 2) and t1.tolist() == [[7.0, 8.0]], t1
     if rank == 0:
         print("GATHER_OK", len(idx), world)
     import torch.distributed as dist

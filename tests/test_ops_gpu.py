@@ -342,19 +342,35 @@ def test_homo_warp_horizon_and_identity(ops):
 
 
 def test_dlt_and_mat3(ops, golden_ops):
+    """DLT solve and the 3x3 chain follow the reference's fp32 arithmetic operation for operation
+    (torch_DLT.py:17-45, flowHomoAdpater.py:105-112): bit-identical to the reference golden and to the C oracle."""
     src, dst = T(golden_ops["dlt_src"]), T(golden_ops["dlt_dst"])
     H = torch.empty(5, 3, 3, device="cuda")
     ops.dlt4(dev(src[0]), dev(dst - src), H, 5, 1.0, 1.0, 1.0)
-    assert (H.cpu() - T(golden_ops["dlt_H"])).abs().max() < 2e-4
+    assert torch.equal(H.cpu(), T(golden_ops["dlt_H"]))
     ops.dlt4(dev(src[0]), dev(dst - src), H, 5, 1.0, 1.0, 8.0)
-    assert (H.cpu() - geom.dlt4(src / 8, dst / 8)).abs().max() < 2e-4
+    assert torch.equal(H.cpu(), geom.dlt4(src / 8, dst / 8))
+    gen = torch.Generator().manual_seed(11)
+    for (w, h) in ((512., 512.), (400., 304.), (1000., 760.)):
+        s = torch.tensor([[0., 0.], [w, 0.], [0., h], [w, h]])
+        mo = (torch.rand(64, 4, 2, generator=gen) - 0.5) * 60
+        Hb = torch.empty(64, 3, 3, device="cuda")
+        ops.dlt4(dev(s), dev(mo), Hb, 64, w / 512.0, h / 512.0, 1.0)
+        mn = torch.stack([mo[..., 0] * w / 512, mo[..., 1] * h / 512], 2)          # flowHomoAdpater.py:244
+        assert torch.equal(Hb.cpu(), geom.dlt4(s[None].expand(64, -1, -1), s[None] + mn))
     M = torch.tensor([[32., 0, 32], [0, 24, 24], [0, 0, 1]])
+    Minv = geom.inverse(M)
     Hc = T(golden_ops["dlt_H"])
     out = torch.empty(5, 3, 3, device="cuda")
-    ops.mat3_sandwich(dev(torch.inverse(M)), dev(Hc), dev(M), out)
-    assert (out.cpu() - torch.inverse(M) @ Hc @ M).abs().max() < 1e-4
-    ops.mat3_sandwich(dev(torch.inverse(M)), dev(Hc), dev(M), out, invert=True)
-    assert (out.cpu() - torch.inverse(M) @ torch.inverse(Hc) @ M).abs().max() < 1e-4
+    ops.mat3_sandwich(dev(Minv), dev(Hc), dev(M), out)
+    assert torch.equal(out.cpu(), geom.matmul3(geom.matmul3(Minv.expand_as(Hc), Hc), M.expand_as(Hc)))
+    ops.mat3_sandwich(dev(Minv), dev(Hc), dev(M), out, invert=True)
+    assert torch.equal(out.cpu(), geom.matmul3(geom.matmul3(Minv.expand_as(Hc), geom.inverse(Hc)), M.expand_as(Hc)))
+    R = torch.randn(200, 3, 3, generator=gen)                                         # general matrices: pivoting paths
+    eye = torch.eye(3)
+    outR = torch.empty(200, 3, 3, device="cuda")
+    ops.mat3_sandwich(dev(eye), dev(R), dev(eye), outR, invert=True)
+    assert torch.equal(outR.cpu(), geom.inverse(R))
 
 
 def test_mesh_bounds(ops, golden_ops):

@@ -2,7 +2,7 @@
 import sys, time, torch
 sys.path.insert(0, '/root/repo')
 import stitch_amd
-from oracle import inputs
+from stitch_amd import data as inputs
 cfg, _ = stitch_amd.load_inference_config("all_img1_with_inpaint_g12_transRef")
 torch.manual_seed(1234)
 model = stitch_amd.build_model(cfg).cuda().eval()

@@ -2,7 +2,7 @@
 import sys, collections, ctypes as C, torch
 sys.path.insert(0, '/root/repo')
 import stitch_amd
-from oracle import inputs
+from stitch_amd import data as inputs
 lib, GemmDesc = stitch_amd._lib.lib, stitch_amd._lib.GemmDesc
 cfg, _ = stitch_amd.load_inference_config("all_img1_with_inpaint_g12_transRef")
 torch.manual_seed(1234)
