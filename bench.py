@@ -1,30 +1,37 @@
 """Headline benchmark: stitched image-pairs/s at 512x512 (BASELINE.json metric) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--workload 512|1024]
 
-A step = one pass of the hot path (``FlowHomoAdpater.forward(type="test_eval")``: 1 homography pass,
-2 FlowFormer++ passes, warp / occlusion / blend) over one synthetic 512x512 pair (BASELINE.json
-configs[1]: 512x512, batch=1).  Pairs are independent, so ranks shard them with no data-path collective
-(weak scaling: every rank runs K pairs); one RCCL all-gather moves the per-pair PSNR at the end.
-Inputs and random-init weights are resident in HBM before the timed region.
+N > 1: if the process was not started by ``torch.distributed.run`` it starts
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`` itself (as a child: this parent
+never touches the GPU) and relays rank 0's JSON line; under the driver's own torchrun launch the ranks run directly.
+
+A step = one pass of the hot path over one synthetic pair:
+  --workload 512  (default, BASELINE.json configs[1]): ``FlowHomoAdpater.forward(type="test_eval")`` on a 512x512 pair,
+                  batch 1 (1 homography pass, 2 FlowFormer++ passes, warp / occlusion / blend), hipGraph replay, 3 pairs in
+                  flight on 3 HIP streams; the single-stream figure is reported beside it (``value_1_in_flight``)
+  --workload 1024 (configs[3]): ``forward(type="test_out")`` on 1024x1024 pairs, 4 distinct pairs per GPU in turn, batch 1
+                  (the canvas is per pair and read back to the host mid-way, so this path is eager, one stream)
+Pairs are independent: ranks shard them with no data-path collective (weak scaling: every rank runs K steps); one RCCL
+all-gather moves the per-pair PSNR at the end.  Inputs and random-init weights are resident in HBM before the timed region.
 
 Besides the contract fields the JSON line carries
-  roofline      -- the dominant kernel (fp32-MFMA implicit GEMM family, `conv_gemm_kernel`): algorithmic
-                   FLOPs of its launches in one step / their summed HIP-event durations, vs the 157.3 TFLOP/s
-                   fp32 matrix peak (MI355X_MICROARCH.md); measured on an instrumented step after the
-                   timed region (events on torch's current stream, where the kernels are launched)
-  corr_volume   -- the all-pairs correlation kernel alone (B=8, BASELINE.json configs[2]) against both roofs
+  roofline      -- the dominant kernel family (fp32-MFMA implicit GEMM): algorithmic FLOPs of its launches in one step /
+                   their summed HIP-event durations vs the 157.3 TFLOP/s fp32 matrix peak; measured on an instrumented step
+                   after the timed region (events on the stream the kernels are launched on); ``traffic`` = HBM bytes per
+                   STEP of that family from the committed PMC passes, ``algorithmic_bytes`` = sum of A+W+C of its launches
+  corr_volume   -- the all-pairs correlation kernel alone (B=8, configs[2]) against both roofs
   cpu_baseline  -- the CPU oracle (torch-CPU port of the reference path) timed on this host, rank 0, N=1
+  parity        -- HIP output vs that oracle output on the same pair: dPSNR / dSSIM of the evaluate.py metric, flow error
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,10 +40,58 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 HBM_PEAK_GBS = 8000.0
 
 
-def instrumented_step(model, a, b, ops):
-    """Run one step with a HIP-event pair around every st_conv_gemm launch (library observer hook, so the
-    GEMMs enqueued by the operator-level entry points are seen too); return (flops, ms, launches)."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=("512", "1024"), default="512")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-corr-roofline", action="store_true", help="skip the stand-alone corr-volume timing (PMC passes)")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
+    ap.add_argument("--streams", type=int, default=3, help="independent forwards in flight per GPU (one hipGraph + HIP stream each)")
+    ap.add_argument("--batch", type=int, default=1, help="pairs per forward: 1 = BASELINE configs[1] (default), 8 = configs[2]")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL; gloo for CPU rehearsal of the launcher)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher/collective plumbing only: no GPU, no model (tests/test_dist_cpu.py)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------- launcher (no GPU use)
+def launcher_command(args, port):
+    """The torchrun command line the parent starts for ``--gpus N`` (kept separate so the CPU test can check it)."""
+    fwd = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
+           "--streams", str(args.streams), "--batch", str(args.batch), "--backend", args.backend]
+    for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-corr-roofline", args.no_corr_roofline),
+                     ("--eager", args.eager), ("--dry-run", args.dry_run)):
+        if on:
+            fwd.append(flag)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + fwd
+
+
+def launch_ranks(args):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(launcher_command(args, port), env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(proc.stdout)
+        raise SystemExit(proc.returncode or 1)
+    print(line, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------- measurements
+def instrumented_step(run_step):
+    """Run one step with a HIP-event pair around every st_conv_gemm launch (library observer hook, so the GEMMs enqueued by
+    the operator-level entry points are seen too); returns (flops, ms, launches, algorithmic bytes)."""
     import ctypes as C
+    import torch
     import stitch_amd
     lib, GemmDesc = stitch_amd._lib.lib, stitch_amd._lib.GemmDesc
     rec, open_ev = [], []
@@ -47,21 +102,25 @@ def instrumented_step(model, a, b, ops):
         ev.record(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream())
         if phase == 0:
             d = desc.contents
-            open_ev.append((2.0 * d.M * d.N * d.K * max(1, d.batch), ev))
+            nb = max(1, d.batch)
+            a_rows = d.M if d.kh * d.kw <= 1 else (d.M // max(1, d.Ho * d.Wo)) * d.H * d.W       # conv: input pixels
+            abytes = 4.0 * nb * (a_rows * d.Cin + d.N * d.K + d.M * d.N)                         # A + W + C, fp32
+            open_ev.append((2.0 * d.M * d.N * d.K * nb, abytes, ev))
         else:
-            flops, e0 = open_ev.pop()
-            rec.append((flops, e0, ev))
+            flops, abytes, e0 = open_ev.pop()
+            rec.append((flops, abytes, e0, ev))
 
     lib.st_set_gemm_observer(C.cast(observer, C.c_void_p), None)
     try:
-        model(a, b, type="test_eval")
+        run_step()
         torch.cuda.synchronize()
     finally:
         lib.st_set_gemm_observer(None, None)
-    return sum(f for f, _, _ in rec), sum(e0.elapsed_time(e1) for _, e0, e1 in rec), len(rec)
+    return (sum(r[0] for r in rec), sum(r[2].elapsed_time(r[3]) for r in rec), len(rec), sum(r[1] for r in rec))
 
 
 def corr_roofline(ops, B=8, N=4096, C=256, iters=10):
+    import torch
     f1 = torch.randn(B, N, C, device="cuda")
     f2 = torch.randn(B, N, C, device="cuda")
     vol = torch.empty(B, N, N, device="cuda")
@@ -80,9 +139,11 @@ def corr_roofline(ops, B=8, N=4096, C=256, iters=10):
                 tflops=flops / ms / 1e9, fma_frac=flops / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, batch=B)
 
 
-def cpu_baseline():
-    """CPU oracle (port of the reference path) on one 512x512 pair, all host cores."""
-    from oracle import adapter as oadapter
+def cpu_baseline_and_parity(model, ops):
+    """CPU oracle (port of the reference path) on one 512x512 pair, all host cores; then the HIP path on the same pair with
+    the same (seeded) weights: quality difference in the reference's own metric (evaluate.py:44-65)."""
+    import torch
+    from oracle import adapter as oadapter            # checker + reported CPU baseline only (never the product path)
     from oracle import spec
     from stitch_amd.data import structured_pair
     sd = spec.seeded_state_dict(1234)
@@ -94,111 +155,173 @@ def cpu_baseline():
     torch.set_num_threads(max(1, min(ncpu, 16)))     # the GPU box grants a 16-core share per GPU
     with torch.no_grad():
         t0 = time.time()
-        oadapter.forward_test_eval(sd, a, b)
+        ref = oadapter.forward_test_eval(sd, a, b)
         dt = time.time() - t0
-    return dict(value=1.0 / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+    base = dict(value=1.0 / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
                 sample="1 pair, 512x512, type=test_eval (1 homography + 2 FlowFormer passes), torch-CPU fp32 oracle")
+    keep = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(sd, strict=True)
+    try:
+        got = model(a.cuda(), b.cuda(), type="test_eval")
+        m_hip = ops.masked_psnr_ssim(a.cuda(), got["final_warp_output"])[0].cpu()
+        m_ref = ops.masked_psnr_ssim(a.cuda(), ref["final_warp_output"].cuda())[0].cpu()
+        dflow = (got["flow_predictions"][0].cpu() - ref["flow_predictions"][0]).abs().flatten()
+        flips = int((got["origin_occlusion_mask"].cpu() != ref["origin_occlusion_mask"]).sum())
+        parity = {"pair": "structured 512x512 seed 7, seeded weights 1234, HIP vs CPU oracle (reference arithmetic)",
+                  "psnr_hip": m_hip[0].item(), "psnr_oracle": m_ref[0].item(), "d_psnr_db": abs(m_hip[0] - m_ref[0]).item(),
+                  "d_ssim": abs(m_hip[1] - m_ref[1]).item(), "H_max_abs": (got["H"].cpu() - ref["H"]).abs().max().item(),
+                  "flow_max_px": dflow.max().item(), "flow_p99_px": dflow.kthvalue(int(0.99 * dflow.numel())).values.item(),
+                  "occlusion_flips": flips, "of_pixels": 512 * 512,
+                  "note": "metric kernel = evaluate.py:44-65 restated from skimage 0.19's published algorithm (skimage itself "
+                          "absent: parity vs skimage unpinned); 8-pair distribution: profiles/r2_parity.json"}
+    finally:
+        model.load_state_dict(keep, strict=True)
+    return base, parity
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-corr-roofline", action="store_true", help="skip the stand-alone corr-volume timing (PMC passes)")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
-    ap.add_argument("--streams", type=int, default=3, help="independent forwards in flight per GPU (one hipGraph + HIP stream each)")
-    ap.add_argument("--batch", type=int, default=1, help="pairs per forward: 1 = BASELINE configs[1] (default), 8 = configs[2]")
-    args = ap.parse_args()
-
+# ---------------------------------------------------------------------------------------------- one rank
+def worker(args):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
     dist = None
+    if args.dry_run:                                   # launcher + collective plumbing, CPU only
+        import torch.distributed as dist
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        vals = torch.full((args.steps,), float(rank))
+        gathered = [torch.empty_like(vals) for _ in range(world)]
+        dist.all_gather(gathered, vals)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "stitched image-pairs/s at 512x512", "value": 0.0, "unit": "pairs/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "gathered_ranks": sorted({int(g[0]) for g in gathered})}), flush=True)
+        dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local)
     if "RANK" in os.environ and "MASTER_PORT" in os.environ:      # launched by torch.distributed.run (also with 1 rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,      # "nccl" is RCCL on ROCm
-                                device_id=torch.device("cuda", local))
+        dist.init_process_group(args.backend, rank=rank, world_size=world,      # "nccl" is RCCL on ROCm
+                                device_id=torch.device("cuda", local) if args.backend == "nccl" else None)
 
     import stitch_amd
-    from stitch_amd.data import structured_pair     # deterministic synthetic pairs
+    from stitch_amd.data import structured_pair      # deterministic synthetic pairs
     ops = stitch_amd.ops
     cfg, _ = stitch_amd.load_inference_config("all_img1_with_inpaint_g12_transRef")
     torch.manual_seed(1234)
     model = stitch_amd.build_model(cfg).cuda().eval()          # random-init weights of the architecture
-    pairs = [structured_pair(512, 512, seed=7 + rank + 100 * i) for i in range(max(1, args.batch))]
-    a, b = torch.cat([p[0] for p in pairs]).cuda(), torch.cat([p[1] for p in pairs]).cuda()
-    nb = a.shape[0]
-
-    nstreams = 1 if args.eager else max(1, args.streams)
-    fwds = [(lambda x, y: model(x, y, type="test_eval")) if args.eager else model.graphed("test_eval") for _ in range(nstreams)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
-
-    def step(i=0):
-        """one pair through the hot path on stream i % nstreams (+ its PSNR vs image 1)"""
-        with torch.cuda.stream(streams[i % nstreams]):
-            o = fwds[i % nstreams](a, b)
-            return ops.masked_psnr_ssim(a, o["final_warp_output"])[0]      # evaluate.py:53-59 metric, HIP kernel, fp64 (psnr, ssim) of pair 0 (all pairs computed)
 
     def log(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+    big = args.workload == "1024"
+    if big:
+        # configs[3]: 1024x1024 pairs, 4 per GPU, each its own test_out call (batch 1: the canvas is per pair)
+        pairs = [tuple(t.cuda() for t in structured_pair(1024, 1024, seed=900 + 8 * rank + i, shift=(11 - 3 * i, 5 * i - 9)))
+                 for i in range(4)]
+        nb, nstreams = 1, 1
+        streams = [torch.cuda.current_stream()]
+
+        def step(i=0):
+            a, b = pairs[i % len(pairs)]
+            o = model(a, b, type="test_out")
+            return o["blend_image"].float().mean().double().reshape(1)         # a per-pair scalar for the final gather
+        a, b = pairs[0]
+    else:
+        ps = [structured_pair(512, 512, seed=7 + rank + 100 * i) for i in range(max(1, args.batch))]
+        a, b = torch.cat([p[0] for p in ps]).cuda(), torch.cat([p[1] for p in ps]).cuda()
+        nb = a.shape[0]
+        nstreams = 1 if args.eager else max(1, args.streams)
+        fwds = [(lambda x, y: model(x, y, type="test_eval")) if args.eager else model.graphed("test_eval") for _ in range(nstreams)]
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
+
+        def step(i=0, n_in_flight=None):
+            """one pair through the hot path on stream i % nstreams (+ its PSNR vs image 1)"""
+            k = i % (n_in_flight or nstreams)
+            with torch.cuda.stream(streams[k]):
+                o = fwds[k](a, b)
+                return ops.masked_psnr_ssim(a, o["final_warp_output"])[0]      # evaluate.py:53-59 metric, HIP kernel, fp64 (psnr, ssim)
+
+    def timed(nsteps, **kw):
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        vals = [step(i, **kw) for i in range(nsteps)]
+        for st in streams[1:]:
+            torch.cuda.current_stream().wait_stream(st)
+        metric = torch.stack(vals)
+        if dist:
+            gathered = [torch.empty_like(metric) for _ in range(world)]
+            dist.all_gather(gathered, metric)          # the path's only collective: per-pair metric reduction
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device="cuda")
+        if dist:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return tmax.item()
+
     log("model built, warming up")
     for i in range(max(args.warmup, nstreams)):
         step(i)
-    torch.cuda.synchronize()
     log("timed region")
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    vals = [step(i) for i in range(args.steps)]
-    for st in streams[1:]:
-        torch.cuda.current_stream().wait_stream(st)
-    psnr = torch.stack(vals)
-    if dist:
-        gathered = [torch.empty_like(psnr) for _ in range(world)]
-        dist.all_gather(gathered, psnr)            # the path's only collective: per-pair metric reduction
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device="cuda")
-    if dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    dt = timed(args.steps)
+    dt1 = None
+    if not big and nstreams > 1:
+        dt1 = timed(max(10, args.steps // 2), n_in_flight=1)       # same graphs, one pair in flight (latency-bound figure)
 
     if rank == 0:
         log(f"timed region done: {dt:.3f} s for {args.steps} steps; instrumented step")
-        flops, gemm_ms, launches = instrumented_step(model, a, b, ops)
-        log("corr-volume roofline + cpu baseline")
+        if big:
+            flops, gemm_ms, launches, abytes = instrumented_step(lambda: model(a, b, type="test_out"))
+        else:
+            flops, gemm_ms, launches, abytes = instrumented_step(lambda: model(a, b, type="test_eval"))
         tf = flops / gemm_ms / 1e9
-        traffic = None                  # HBM bytes per launch of the dominant kernel from the committed PMC passes
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        traffic, tsrc = None, None             # HBM bytes per step of the GEMM family from the committed PMC passes
+        for name in ("r2_traffic.json", "r1_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath) and not big and nb == 1:
+                t = json.load(open(tpath))
+                traffic = t["fetch_bytes_per_step"] + t["write_bytes_per_step"]
+                tsrc = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied)"
+                break
+        wl = ("synthetic 1024x1024 pairs, 4 per GPU, batch=1, FlowHomoAdpater.forward(type=test_out)" if big else
+              f"UDIS-D-shaped 512x512 pairs, batch={nb}, FlowHomoAdpater.forward(type=test_eval)")
         out = {
-            "metric": "stitched image-pairs/s at 512x512", "value": world * args.steps * nb / dt, "unit": "pairs/s",
+            "metric": "stitched image-pairs/s at 512x512" if not big else "stitched image-pairs/s at 1024x1024",
+            "value": world * args.steps * nb / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"UDIS-D-shaped 512x512 pairs, batch={nb}, FlowHomoAdpater.forward(type=test_eval)",
-                       "pairs_per_step_per_gpu": nb, "launch": "eager" if args.eager else "hipGraph replay", "pairs_in_flight": nstreams * nb, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
+            "config": {"workload": wl, "pairs_per_step_per_gpu": nb,
+                       "launch": "eager" if (args.eager or big) else "hipGraph replay", "pairs_in_flight": nstreams * nb,
+                       "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective, one all_gather of per-pair metrics"},
+            "value_1_in_flight": None if dt1 is None else world * max(10, args.steps // 2) * nb / dt1,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_dma_kernel + conv_gemm_kernel (fp32 MFMA implicit GEMM: all st_conv_gemm launches of one step)",
                          "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied)",
-                         "launches_per_step": launches, "gflop_per_step": flops / 1e9,
+                         "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)", "traffic_source": tsrc,
+                         "algorithmic_bytes": abytes, "launches_per_step": launches, "gflop_per_step": flops / 1e9,
                          "kernel_ms_per_step": gemm_ms},
             "corr_volume": None if args.no_corr_roofline else corr_roofline(ops),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            log("cpu baseline + parity")
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(model, ops)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)          # parent: starts the N ranks as a child process, relays the JSON line
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -628,6 +628,41 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // K-blocked accumulation: one fmaf chain over all of K has a rounding error that grows like sqrt(K); the reference's
+    // CPU GEMM (MKL) accumulates in K blocks of a few hundred, and at K >= 512 a single chain is measurably worse than it
+    // (rms 5.7e-7 vs 3.4e-7 at K = 1024, 8.6e-7 vs 3.1e-7 at K = 2304; profiles/r2_parity_trace_*.txt).  So the chain is
+    // cut every KBLK K steps (256 k): the running tile is folded into `tot` and restarted from zero.  16 v_add per
+    // 32x32 sub-tile every 128 MFMAs; K <= 256 never folds.
+    constexpr int KBLK = 2 * STAGES;
+    f32x16 tot[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    auto fold = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                tot[i][j] = tot[i][j] + acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto unfold = [&]() {                           // result of a blocked tile back into acc (epilogue operand)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = acc[i][j] + tot[i][j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     const int li = lane & 31, lh = lane >> 5;
     const int swz = (li >> 1) & 7;
@@ -710,7 +745,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
             for (int mt = 0; mt < nmt; ++mt) {
                 gemm_epilogue_load<TM, TN>(d, eop, (tile_m + mt * G) * BM, n0, wm, wn, li, lh, 1);   // lands under the MFMAs
                 __builtin_amdgcn_sched_barrier(0);
-                for (int tb = mt * nkt; tb < (mt + 1) * nkt; tb += STAGES) {    // nkt % STAGES == 0: stage == s
+                for (int tb = mt * nkt, kb = STAGES; tb < (mt + 1) * nkt; tb += STAGES, kb += STAGES) {    // nkt % STAGES == 0: stage == s
                     if (tb + 2 * STAGES - 1 <= ntiles) {
 #pragma unroll
                         for (int s = 0; s < STAGES; ++s) tile_body(st_true{}, s, tb + s);
@@ -718,7 +753,9 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
 #pragma unroll
                         for (int s = 0; s < STAGES; ++s) tile_body(st_false{}, s, tb + s);
                     }
+                    if (kb % KBLK == 0 && kb < nkt) fold();
                 }
+                if (nkt > KBLK) unfold();
                 gemm_epilogue_store<TM, TN>(d, C, acc, eop, (tile_m + mt * G) * BM, n0, wm, wn, li, lh, 1, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -732,12 +769,15 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
             for (; tb + 2 * STAGES - 1 <= ntiles; tb += STAGES) {       // every tile of the block still feeds a new one
 #pragma unroll
                 for (int s = 0; s < STAGES; ++s) tile_body(st_true{}, s, tb + s);
+                if ((tb + STAGES) % KBLK == 0) fold();
             }
             for (; tb < ntiles; tb += STAGES) {
 #pragma unroll
                 for (int s = 0; s < STAGES; ++s)
                     if (tb + s < ntiles) tile_body(st_false{}, s, tb + s);
+                if ((tb + STAGES) % KBLK == 0 && tb + STAGES < ntiles) fold();
             }
+            if (ntiles > KBLK) unfold();
         }
     }
 #undef ST_GAP

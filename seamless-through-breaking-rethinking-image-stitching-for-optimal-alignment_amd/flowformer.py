@@ -410,6 +410,53 @@ class FlowFormer(ParamTree):
         return x, short
 
     # ------------------------------------------------------------------ decoder
+    def _gru_tables(self, inp, B, H1, W1):
+        """per-pass SepConvGRU tables: conv over the constant `inp` channels + bias, [z | r | q] for each half."""
+        D = self._pk["dec"]
+        gru_geom = {"1": (B, H1, W1, 1, 5, 1, 1, 0, 2), "2": (B, H1, W1, 5, 1, 1, 1, 2, 0)}
+        tabs = {}
+        for sfx in ("1", "2"):
+            tabs[sfx] = _new(inp.shape[0], 384, inp.device)
+            ops.conv_gemm(inp, D["inp" + sfx][0], tabs[sfx], geom=gru_geom[sfx], bias=D["inp" + sfx][1])
+        return tabs
+
+    def _update_state(self, R, B, N, dev):
+        """work buffers of the refinement loop.  hxA = [h | motion(126)+flow(2) | motion_global], hxB = [r*h | same];
+        corr = [cost_forward 81 | 3 zero | cost_global 64]."""
+        return dict(hxA=_new(R, 384, dev), hxB=_new(R, 384, dev), corr=_new(R, 148, dev, zero=True), flow4=_new(R, 4, dev),
+                    cor1=_new(R, 256, dev), corflo=_new(R, 256, dev), flo1=_new(R, 128, dev),
+                    vT=torch.empty((B, 128, N), device=dev), zbuf=_new(R, 128, dev), fh=_new(R, 256, dev))
+
+    def _update_block(self, S, coords1, attn, gru_tab, B, H1, W1):
+        """GMAUpdateBlock.forward (gru.py:322-334) without the mask head: BasicMotionEncoder (gru.py:246-254), GMA
+        aggregate (gma.py:102-115), SepConvGRU (gru.py:44-59), flow head (gru.py:5-13); coords1 += delta_flow
+        (decoder.py:329).  Reads S['corr'] (cost_forward | cost_global), updates S['hxA'][:, :128] (net) and coords1."""
+        D = self._pk["dec"]
+        N = H1 * W1
+        hxA, hxB, corr, flow4 = S["hxA"], S["hxB"], S["corr"], S["flow4"]
+        g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
+        ops.flow_from_coords(coords1, flow4, hxA[:, 254:256], B, H1, W1)                          # :321, gru.py:254
+        ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu")
+        ops.conv_gemm(S["cor1"], D["convc2"][0], S["corflo"][:, :192], geom=g3, bias=D["convc2"][1], act="relu")
+        ops.conv_gemm(flow4, D["convf1"][0], S["flo1"], geom=(B, H1, W1, 7, 7, 1, 1, 3, 3), bias=D["convf1"][1], act="relu")
+        ops.conv_gemm(S["flo1"], D["convf2"][0], S["corflo"][:, 192:], geom=g3, bias=D["convf2"][1], act="relu")
+        ops.conv_gemm(S["corflo"], D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu")
+        # GMA aggregate: v^T = Wv . mf^T, out = mf + gamma * attn @ v
+        ops.gma_aggregate(attn, hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], hxA[:, 256:], B, N)
+        ops.copy2d(hxA[:, 128:], hxB[:, 128:])
+        # SepConvGRU: horizontal 1x5 then vertical 5x1
+        ops.sepconv_gru(hxA, hxB, S["zbuf"], gru_tab["1"], gru_tab["2"], D["zr1"], D["q1"], D["zr2"], D["q2"], B, H1, W1)
+        ops.conv_gemm(hxA[:, :128], D["fh1"][0], S["fh"], geom=g3, bias=D["fh1"][1], act="relu")
+        ops.conv_gemm(S["fh"], D["fh2"][0], coords1, geom=g3, bias=D["fh2"][1], epi="add", aux1=coords1)
+
+    def _mask_head(self, S, B, H1, W1):
+        """mask = .25 * conv1x1(relu(conv3x3(net))) (gru.py:315-318,333) -> rows [R, 576]."""
+        D = self._pk["dec"]
+        ops.conv_gemm(S["hxA"][:, :128], D["m0"][0], S["fh"], geom=(B, H1, W1, 3, 3, 1, 1, 1, 1), bias=D["m0"][1], act="relu")
+        mask = _new(S["hxA"].shape[0], 576, S["hxA"].device)
+        ops.conv_gemm(S["fh"], D["m2"][0], mask, bias=D["m2"][1], alpha=0.25)
+        return mask
+
     def _decoder(self, mem, mem_short, ctx, cost_maps, B, H1, W1, iters, trace=None):
         """MemoryDecoder.forward eval branch (decoder.py:262-344)."""
         D = self._pk["dec"]
@@ -417,16 +464,11 @@ class FlowFormer(ParamTree):
         N = H1 * W1
         R = B * N
         nl = self._pk["latents"].shape[0]
-        hxA, hxB = _new(R, 384, dev), _new(R, 384, dev)          # [h | motion(126)+flow(2) | motion_global], [r*h | same]
+        S = self._update_state(R, B, N, dev)
         inp = _new(R, 128, dev)
-        ops.conv_gemm(ctx, D["proj_net"][0], hxA[:, :128], bias=D["proj_net"][1], act="tanh")
+        ops.conv_gemm(ctx, D["proj_net"][0], S["hxA"][:, :128], bias=D["proj_net"][1], act="tanh")
         ops.conv_gemm(ctx, D["proj_inp"][0], inp, bias=D["proj_inp"][1], act="relu")
-        # per-pass GRU tables: conv over the constant `inp` channels + bias, [z | r | q] for each half
-        gru_geom = {"1": (B, H1, W1, 1, 5, 1, 1, 0, 2), "2": (B, H1, W1, 5, 1, 1, 1, 2, 0)}
-        gru_tab = {}
-        for sfx in ("1", "2"):
-            gru_tab[sfx] = _new(R, 384, dev)
-            ops.conv_gemm(inp, D["inp" + sfx][0], gru_tab[sfx], geom=gru_geom[sfx], bias=D["inp" + sfx][1])
+        gru_tab = self._gru_tables(inp, B, H1, W1)
         # GMA attention, once (gma.py:54-76)
         qk = _new(R, 256, dev)
         attn = torch.empty((B, N, N), device=dev)
@@ -439,37 +481,15 @@ class FlowFormer(ParamTree):
         ops.conv_gemm(mem, ca["kv"][0], kv, aux0=kv0)
         coords1 = _new(R, 2, dev)
         ops.coords_grid(coords1, B, H1, W1)
-        corr = _new(R, 148, dev, zero=True)
-        flow4 = _new(R, 4, dev)
-        cor1, corflo, flo1 = _new(R, 256, dev), _new(R, 256, dev), _new(R, 128, dev)
-        vT = torch.empty((B, 128, N), device=dev)
-        zbuf, fh = _new(R, 128, dev), _new(R, 256, dev)
-        g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
         for it in range(iters):
-            ops.cost_lookup9x9(cost_maps, coords1, corr, R, H1, W1)                                   # decoder.py:291
+            ops.cost_lookup9x9(cost_maps, coords1, S["corr"], R, H1, W1)                              # decoder.py:291
             # flow_token_encoder + cost-memory cross attention + FFN: one fused launch (decoder.py:305-312)
-            ops.decoder_token_chain(corr, coords1, kv, D["chain16"], R, nl)
-            ops.flow_from_coords(coords1, flow4, hxA[:, 254:256], B, H1, W1)                          # :321, gru.py:254
-            # BasicMotionEncoder (gru.py:246-254)
-            ops.conv_gemm(corr, D["convc1"][0], cor1, bias=D["convc1"][1], act="relu")
-            ops.conv_gemm(cor1, D["convc2"][0], corflo[:, :192], geom=g3, bias=D["convc2"][1], act="relu")
-            ops.conv_gemm(flow4, D["convf1"][0], flo1, geom=(B, H1, W1, 7, 7, 1, 1, 3, 3), bias=D["convf1"][1], act="relu")
-            ops.conv_gemm(flo1, D["convf2"][0], corflo[:, 192:], geom=g3, bias=D["convf2"][1], act="relu")
-            ops.conv_gemm(corflo, D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu")
-            # GMA aggregate (gma.py:102-115): v^T = Wv . mf^T, out = mf + gamma * attn @ v
-            ops.gma_aggregate(attn, hxA[:, 128:256], D["to_v"], D["gamma"], vT, hxA[:, 256:], B, N)
-            ops.copy2d(hxA[:, 128:], hxB[:, 128:])
-            # SepConvGRU (gru.py:44-59): horizontal 1x5 then vertical 5x1
-            ops.sepconv_gru(hxA, hxB, zbuf, gru_tab["1"], gru_tab["2"], D["zr1"], D["q1"], D["zr2"], D["q2"], B, H1, W1)
-            # flow head (gru.py:5-13) and coords1 += delta_flow (decoder.py:329)
-            ops.conv_gemm(hxA[:, :128], D["fh1"][0], fh, geom=g3, bias=D["fh1"][1], act="relu")
-            ops.conv_gemm(fh, D["fh2"][0], coords1, geom=g3, bias=D["fh2"][1], epi="add", aux1=coords1)
+            ops.decoder_token_chain(S["corr"], coords1, kv, D["chain16"], R, nl)
+            self._update_block(S, coords1, attn, gru_tab, B, H1, W1)
             if trace is not None:
-                trace.append(dict(coords1=coords1.clone(), net=hxA[:, :128].clone(), corr=corr.clone()))
+                trace.append(dict(coords1=coords1.clone(), net=S["hxA"][:, :128].clone(), corr=S["corr"].clone()))
         # mask head + convex upsampling, last iteration only (gru.py:315-318,333; decoder.py:214-225)
-        ops.conv_gemm(hxA[:, :128], D["m0"][0], fh, geom=g3, bias=D["m0"][1], act="relu")
-        mask = _new(R, 576, dev)
-        ops.conv_gemm(fh, D["m2"][0], mask, bias=D["m2"][1], alpha=0.25)
+        mask = self._mask_head(S, B, H1, W1)
         flow_up = torch.empty((B, 2, 8 * H1, 8 * W1), device=dev)
         ops.convex_upsample(coords1, mask, flow_up, B, H1, W1)
         return flow_up, coords1

@@ -48,3 +48,23 @@ def test_shard_is_a_partition():
         assert seen == list(range(1106))
     t = sd.gather_metrics([0, 2], [[1.0], [3.0]], 3)
     assert t[0, 0] == 1.0 and t[2, 0] == 3.0 and t[1, 0] != t[1, 0]
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`bench.py --gpus 2` (not under torchrun) must start 2 ranks itself and relay ONE JSON line with n_gpus = 2;
+    rehearsed on CPU with gloo and --dry-run (no model, no GPU): launcher arguments + rendezvous + all_gather."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "1024", "--backend", "gloo", "--dry-run"])
+    cmd = bench.launcher_command(args, 29544)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--master-addr" in cmd
+    assert cmd[cmd.index("--workload") + 1] == "1024" and cmd[cmd.index("--steps") + 1] == "3"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", "--dry-run"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["gathered_ranks"] == [0, 1]

@@ -1,0 +1,163 @@
+"""Stage-wise parity at BASELINE size (512x512) with the oracle's intermediates held fixed, and the north-star quality
+number (PSNR / SSIM of evaluate.py:44-65, HIP path vs CPU oracle on the same pairs).
+
+Why three-way comparisons: with the seeded random weights the 12 recurrent refinements amplify rounding differences by
+~1.6x per iteration (profiles/r2_parity_trace_512x512.txt), so the fp32 oracle -- which IS the reference's arithmetic,
+pinned bit for bit -- sits 1.4e-2 px (max) / 3.4e-3 px (p99) away from the same algorithm evaluated in fp64.  A bound on
+|HIP - oracle32| below that level would test summation order, not correctness.  The enforceable statement is that the
+HIP result is as close to the exact (fp64) answer as the reference's own fp32 evaluation is, stage by stage, with the
+upstream stage's output taken from the oracle so that differences cannot accumulate across stages."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import adapter as oadapter  # noqa: E402
+from oracle import geom, nets, spec  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model(seeded_sd):
+    import stitch_amd
+    cfg, _ = stitch_amd.load_inference_config("all_img1_with_inpaint_g12_transRef")
+    m = stitch_amd.build_model(cfg)
+    m.load_state_dict(seeded_sd, strict=True)
+    return m.cuda().eval()
+
+
+@pytest.fixture(scope="module")
+def ref512(seeded_sd):
+    """oracle forward (fp32 = reference arithmetic) of the structured 512x512 pair, with its intermediates."""
+    from stitch_amd.data import structured_pair
+    a, b = structured_pair(512, 512, seed=7)
+    st = {}
+    with torch.no_grad():
+        out = oadapter.forward_test_eval(seeded_sd, a, b, stages=st)
+    return dict(a=a, b=b, out=out, motion=st["motion"], flow_ji=st["flow_ji"])
+
+
+def _q(d, q=0.99):
+    d = d.flatten()
+    return d.kthvalue(max(1, int(q * d.numel()))).values.item()
+
+
+def test_homography_stage_is_bit_exact_given_oracle_motion(model, ref512):
+    """DLT + 3x3 chain + homography transformer (flowHomoAdpater.py:89-113) on the oracle's corner offsets: H, output_H and
+    output_H_inv are bit-identical to the oracle's (fp32 arithmetic restated operation for operation)."""
+    import stitch_amd
+    ops = stitch_amd.ops
+    a, b, o = ref512["a"].cuda(), ref512["b"].cuda(), ref512["out"]
+    dev = a.device
+    H = torch.empty((1, 3, 3), device=dev)
+    ops.dlt4(model._corners(dev, 512, 512), ref512["motion"].cuda().contiguous(), H, 1, 1.0, 1.0, 8.0)
+    assert torch.equal(H.cpu(), o["H"])
+    M, Minv = model._scale_pair(dev, 512 / 8, 512 / 8)
+    H_mat, H_inv_mat = torch.empty_like(H), torch.empty_like(H)
+    ops.mat3_sandwich(Minv, H, M, H_mat)
+    ops.mat3_sandwich(Minv, H, M, H_inv_mat, invert=True)
+    out_H = ops.homo_warp(b, H_mat.view(1, 9), (512, 512), n_ones=3)
+    out_Hi = ops.homo_warp(a, H_inv_mat.view(1, 9), (512, 512), n_ones=3)
+    assert torch.equal(out_H.cpu(), o["output_H"])
+    assert torch.equal(out_Hi.cpu(), o["output_H_inv"])
+
+
+def test_flow_stage_512_given_oracle_warp2(model, ref512, seeded_sd):
+    """FlowFormer++ (both directions, one batch) fed the ORACLE's warp2: against the fp32 oracle and against the same
+    network evaluated in fp64."""
+    a, o = ref512["a"], ref512["out"]
+    warp2 = o["output_H"][:, 0:3].contiguous()
+    fij, fji = model.predict_flow_pair(a.cuda(), warp2.cuda())
+    fij, fji = fij.cpu(), fji.cpu()
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in seeded_sd.items()}
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.no_grad():
+            f64 = nets.flowformer(nets.W(sd64, "flow_backbone."), a.double(), warp2.double())[0]
+    finally:
+        torch.set_default_dtype(torch.float32)
+    o32 = o["flow_predictions"][0]
+    d_ho, d_h64, d_o64 = (fij - o32).abs(), (fij.double() - f64).abs(), (o32.double() - f64).abs()
+    d_ji = (fji - ref512["flow_ji"]).abs()
+    rec = dict(hip_o32_max=d_ho.max().item(), hip_o32_p99=_q(d_ho), hip_o64_max=d_h64.max().item(), hip_o64_p99=_q(d_h64),
+               o32_o64_max=d_o64.max().item(), o32_o64_p99=_q(d_o64), ji_hip_o32_max=d_ji.max().item(), ji_hip_o32_p99=_q(d_ji))
+    print("[flow stage 512, px]", json.dumps(rec))
+    # as close to the exact answer as the reference's own fp32 evaluation (x1.5 head-room for a different summation order)
+    assert rec["hip_o64_max"] <= 1.5 * rec["o32_o64_max"] + 1e-3, rec
+    assert rec["hip_o64_p99"] <= 1.5 * rec["o32_o64_p99"] + 1e-4, rec
+    # and absolute: |flow| ~ 10 px after 12 chaotic refinements; the reference moves by 1.4e-2 / 3.4e-3 against fp64
+    assert rec["hip_o32_max"] < 4e-2 and rec["hip_o32_p99"] < 1e-2, rec
+    assert rec["ji_hip_o32_max"] < 4e-2 and rec["ji_hip_o32_p99"] < 1e-2, rec
+
+
+def test_flow_warp_given_oracle_flow(ref512):
+    """warp() = grid_sample(bilinear, zeros, align_corners=True) (core/warp_utils.py:71-80) on the oracle's flow: the
+    coordinate round trip and the fused accumulation follow ATen's CPU kernel, north_star bound 1e-3."""
+    import stitch_amd
+    o = ref512["out"]
+    flow, x = o["flow_predictions"][0], o["output_H"]
+    got = stitch_amd.ops.flow_warp(x.cuda(), flow.cuda()).cpu()
+    ref = geom.warp(x, flow)
+    d = (got - ref).abs()
+    print(f"[flow_warp 512] max {d.max().item():.3e}  exact {(d == 0).float().mean().item():.6f}")
+    assert d.max() < 1e-3
+
+
+def test_occlusion_given_oracle_flow_ji(ref512):
+    """range map + threshold (core/warp_utils.py:114-221, flowHomoAdpater.py:180-181) on the oracle's backward flow: the mask
+    is exact except where the range value lies within 1e-5 of the 0.5 threshold (the splat sums 4 weights per source
+    pixel in a different order)."""
+    import stitch_amd
+    ops = stitch_amd.ops
+    fji = ref512["flow_ji"].contiguous()
+    rng_ref = geom.range_map(fji)
+    rng = ops.range_map(fji.cuda())
+    occ = ops.occlusion_from_range(rng, True).cpu()
+    assert (rng.cpu() - rng_ref).abs().max() < 1e-5
+    occ_val = geom.occlusion_wang(ref512["out"]["flow_predictions"][0], fji)
+    occ_ref = (occ_val >= 0.5).float()
+    diff = occ != occ_ref
+    near = (occ_val - 0.5).abs() < 1e-5
+    assert not (diff & ~near).any(), int((diff & ~near).sum())
+    print(f"[occlusion 512] flips {int(diff.sum())} (all within 1e-5 of the threshold)")
+
+
+def test_quality_psnr_ssim_vs_oracle(model, seeded_sd):
+    """north_star: 'PSNR within 0.01 dB of reference'.  8 structured 512x512 pairs through the whole path (HIP) and
+    through the CPU oracle; the evaluate.py metric (masked PSNR / SSIM, HIP kernel st_masked_psnr_ssim) on both outputs.
+    The metric restates skimage 0.19 from its published algorithm (skimage absent, no reference fixture): parity of the
+    metric itself against skimage is unpinned; the DIFFERENCE reported here does not depend on that."""
+    import stitch_amd
+    from stitch_amd.data import structured_pair
+    ops = stitch_amd.ops
+    rows = []
+    for i in range(8):
+        a, b = structured_pair(512, 512, seed=300 + i, shift=(3 * (i % 5) - 6, 7 - 2 * (i % 7)))
+        with torch.no_grad():
+            ref = oadapter.forward_test_eval(seeded_sd, a, b)
+        got = model(a.cuda(), b.cuda(), type="test_eval")
+        m_hip = ops.masked_psnr_ssim(a.cuda(), got["final_warp_output"])[0].cpu()
+        m_ref = ops.masked_psnr_ssim(a.cuda(), ref["final_warp_output"].cuda())[0].cpu()
+        dflow = (got["flow_predictions"][0].cpu() - ref["flow_predictions"][0]).abs()
+        dwarp = (got["final_warp_output"].cpu() - ref["final_warp_output"]).abs()
+        rows.append(dict(pair=i, psnr_hip=m_hip[0].item(), psnr_oracle=m_ref[0].item(), ssim_hip=m_hip[1].item(),
+                         ssim_oracle=m_ref[1].item(), d_psnr=abs(m_hip[0] - m_ref[0]).item(), d_ssim=abs(m_hip[1] - m_ref[1]).item(),
+                         H_exact=bool(torch.equal(got["H"].cpu(), ref["H"])), H_max=(got["H"].cpu() - ref["H"]).abs().max().item(),
+                         flow_max=dflow.max().item(), flow_p99=_q(dflow), warp_p99=_q(dwarp),
+                         occ_flips=int((got["origin_occlusion_mask"].cpu() != ref["origin_occlusion_mask"]).sum()),
+                         overlap_flips=int((got["overlap"].cpu() != ref["overlap"]).sum())))
+        print("[quality]", json.dumps(rows[-1]))
+    summary = dict(pairs=len(rows), d_psnr_max=max(r["d_psnr"] for r in rows), d_ssim_max=max(r["d_ssim"] for r in rows),
+                   flow_max=max(r["flow_max"] for r in rows), flow_p99_max=max(r["flow_p99"] for r in rows),
+                   occ_flips_max=max(r["occ_flips"] for r in rows), overlap_flips_max=max(r["overlap_flips"] for r in rows),
+                   H_max=max(r["H_max"] for r in rows))
+    print("[quality summary]", json.dumps(summary))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(dict(summary=summary, rows=rows), open(os.path.join(ROOT, "gpurun_out", "r2_parity.json"), "w"), indent=1)
+    assert summary["d_psnr_max"] <= 0.01, summary
+    assert summary["d_ssim_max"] <= 1e-4, summary
