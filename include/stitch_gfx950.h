@@ -49,8 +49,7 @@ typedef struct st_gemm_desc {
     float* c2;             /* second output for epi 5 (fused GRU gates): [M, ldc2]                  */
     int32_t ldc2;
     uint32_t a_bytes, w_bytes;  /* filled by the library: extents of A / W for the buffer descriptors  */
-    int32_t precision;     /* 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain); 1: fp32-grade bf16x6 split
-                              (x = x1+x2+x3 exactly in bf16, six partial products, fp32 accumulate)       */
+    int32_t reserved0;     /* must be 0 (was the selector of an experimental split-bf16 kernel, removed)           */
     int64_t batch_stride_aux1;  /* floats; aux1 of batch z starts at aux1 + z * batch_stride_aux1          */
     int32_t dh, dw;        /* conv dilation (0 / 1 = dense): tap (ky,kx) reads pixel (oy*sh-ph+ky*dh, ox*sw-pw+kx*dw);
                               Ho / Wo are the caller's (PyTorch: H + 2*ph - dh*(kh-1) - 1) / sh + 1)            */
@@ -68,6 +67,12 @@ int st_conv_gemm(const st_gemm_desc* desc, void* stream);
  * (also for the GEMMs launched by the operator-level entry points below), so a caller can bracket them with HIP
  * events on `stream`.  NULL switches it off.  Process-wide; do not change it while other threads launch.   */
 int st_set_gemm_observer(void* callback, void* user);
+
+/* Profiling aid: the launch plan the library chose for the calling thread's most recent st_conv_gemm:
+ *   plan4[0] kernel family (0 skinny_gemm, 1 narrow_conv, 2 conv_gemm_kernel [register-staged], 3 conv_gemm_dma_kernel)
+ *   plan4[1] tile_cfg actually used, plan4[2] split_k actually used, plan4[3] 1 = persistent M walk.
+ * Used by tools/gemm_shapes_csv.py to label every launch of a step (profiles/r2_gemm_shapes.csv). */
+int st_gemm_last_plan(int32_t* plan4);
 
 /* sizeof(st_gemm_desc) as compiled into the library (binding self-check; returns the size). */
 int st_abi_gemm_desc_size(void);

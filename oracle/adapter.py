@@ -26,11 +26,14 @@ def _corners(B, w, h):
     return torch.tensor([[0., 0.], [w, 0.], [0., h], [w, h]])[None].expand(B, -1, -1)
 
 
-def forward_test_eval(sd, img1, img2, iters=12, stages=None):
-    """type='test_eval' (flowHomoAdpater.py:83-191).  sd: flat state dict (no 'module.' prefix)."""
+def forward_test_eval(sd, img1, img2, iters=12, stages=None, motion=None):
+    """type='test_eval' (flowHomoAdpater.py:83-191).  sd: flat state dict (no 'module.' prefix).
+    ``motion`` (test hook): corner offsets [B,4,2] to use instead of the homography net's own, to separate the path's
+    sensitivity to its first stage from the later stages' arithmetic."""
     B, _, h, w = img1.shape
     hw, fw = W(sd, "homo_backbone."), W(sd, "flow_backbone.")
-    motion = homo_offsets(hw, img1, img2)
+    if motion is None:
+        motion = homo_offsets(hw, img1, img2)
     src = _corners(B, float(w), float(h))
     H = geom.dlt4(src / 8, (src + motion) / 8)                                       # :96
     M = _scale_mat(w / 8, h / 8)

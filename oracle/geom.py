@@ -152,6 +152,32 @@ def tps_transformer(U, source, target, out_hw):
     return tps_interpolate(U, Tg[:, 0], Tg[:, 1], (oh, ow)), T
 
 
+def tps_indices(source, T, in_hw, out_hw):
+    """Sample indices (x0, x1, y0, y1) [B,oh,ow,4] int32 of the TPS transformer for control points `source` and solved
+    coefficients T [B,2,N+3] (torch_tps_transform.py:96-147 grid + T@grid, :29-41 index arithmetic)."""
+    B, N, _ = source.shape
+    H, W = in_hw
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    xt = torch.from_numpy(cgeom.linspace(-1.0, 1.0, ow))[None, :].expand(oh, -1).reshape(1, 1, -1)
+    yt = torch.from_numpy(cgeom.linspace(-1.0, 1.0, oh))[:, None].expand(-1, ow).reshape(1, 1, -1)
+    px, py = source[:, :, 0:1], source[:, :, 1:2]
+    dd = (xt - px) ** 2 + (yt - py) ** 2
+    rr = dd * torch.log(dd + 1e-6)
+    grid = torch.cat([torch.ones(B, 1, oh * ow), xt.expand(B, -1, -1), yt.expand(B, -1, -1), rr], 1)
+    Tg = torch.matmul(T, grid)
+    f32 = np.float32
+    x = ((Tg[:, 0].numpy().astype(f32) + f32(1.0)) * f32(W) / f32(2.0)).astype(f32)
+    y = ((Tg[:, 1].numpy().astype(f32) + f32(1.0)) * f32(H) / f32(2.0)).astype(f32)
+
+    def toint(v):
+        fl = np.floor(v)
+        bad = ~((fl >= -2147483648.0) & (fl < 2147483648.0))
+        return np.where(bad, -2147483648, np.where(bad, 0, fl).astype(np.int64))
+    x0, y0 = toint(x), toint(y)
+    out = np.stack([np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1), np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)], -1)
+    return torch.from_numpy(out.astype(np.int32).reshape(B, oh, ow, 4))
+
+
 def tps_interpolate(U, xs, ys, out_hw):
     """`_interpolate` of the TPS/homography transformers (torch_tps_transform.py:18-94) in numpy fp32."""
     B, C, H, W = U.shape

@@ -1,0 +1,251 @@
+"""CPU oracle of the TPS post-pipeline -- test infrastructure, torch-CPU fp32.
+
+Restates, function by function, the reference's ``core/inference`` package for the in-tree ("kornia") TPS back-end
+and with no inpainter (``inpaint_fn=None``):
+
+  preprocess                              core/inference/tps_pipline.py:213-244
+  advanced_uniform_sample_border_points   core/inference/sample_point_methods.py:5-128
+  get_point_pairs / shift_points / boundary_src_and_tgt          core/inference/utils.py:61-121
+  sample_init_points                      core/inference/tps_pipline.py:247-336
+  get_tps_transform / warp_points_tps / warp_image_tps           core/inference/tps_methods/kornia_tps.py:26-176
+                                          (the in-tree file re-exports kornia's get_tps_transform / warp_points_tps /
+                                          create_meshgrid; those three are restated from kornia's published definitions:
+                                          PARITY AGAINST KORNIA ITSELF IS UNPINNED -- kornia is not installable here)
+  warp_by_tps ("kornia" branch)           core/inference/tps_pipline.py:339-378
+  tps_H_warp (mask clean-up, mix, blend)  core/inference/tps_pipline.py:20-205
+                                          (cv2.erode / cv2.dilate with an 11x11 rectangle are restated as binary
+                                          min / max filters over the in-image part of the window = OpenCV's default
+                                          morphology border; cv2 is absent: unpinned against cv2 itself)
+
+Pinned to the reference's own functions (imported with kornia / cv2 / torchvision stand-ins) by
+oracle/ref_harness/make_tps_goldens.py -> tests/golden/tps_pipeline.npz, tests/test_oracle_pin.py.
+The reference's default back-end (OpenCV ThinPlateSplineShapeTransformer) and its inpainters are out of scope.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------ preprocess (tps_pipline.py:213-244)
+def preprocess(residual_flow, valid, do_avg_pooling, residual_flow_use_forward, grid_h, grid_w):
+    if do_avg_pooling:
+        size = residual_flow.shape[-2:]
+        k = min(grid_h, grid_w) // 2 * 2 - 1
+        p = (k - 1) // 2
+        residual_flow = F.pad(residual_flow, (p, p, p, p), mode="constant")
+        residual_flow = F.avg_pool2d(residual_flow, kernel_size=k, stride=1, padding=0)
+        residual_flow = F.interpolate(residual_flow, size=size, mode="bilinear", align_corners=False)
+    if not residual_flow_use_forward:
+        residual_flow = -residual_flow.clone()
+    if valid is not None:
+        residual_flow = residual_flow * valid
+    return residual_flow
+
+
+# ------------------------------------------------------------------ border sampling (sample_point_methods.py:5-128)
+def border_ranges(H, W, step, pad_num):
+    """the (x1, y1, x2, y2) ranges between consecutive uniform border samples (:38-69); a range needs i_old != 0."""
+    out = []
+    for y in (pad_num, H - 1 - pad_num):                     # top, bottom
+        i_old = 0
+        for i in range(pad_num, W - pad_num, step):
+            if i_old != 0:
+                out.append((i_old, y, i, y))
+            i_old = i
+    for x in (pad_num, W - 1 - pad_num):                     # left, right
+        i_old = 0
+        for i in range(pad_num, H - pad_num, step):
+            if i_old != 0:
+                out.append((x, i_old, x, i))
+            i_old = i
+    return out
+
+
+def sobel_magnitude(image):
+    """|Sobel_x| and |Sobel_y| per channel, channel mean of each, summed (:70-90) -> [B,1,H,W]."""
+    C = image.shape[1]
+    kx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]]).repeat(C, 1, 1, 1)
+    ky = torch.tensor([[-1., -2., -1.], [0., 0., 0.], [1., 2., 1.]]).repeat(C, 1, 1, 1)
+    gx = torch.abs(F.conv2d(image, kx, padding=1, groups=C)).mean(dim=1, keepdim=True)
+    gy = torch.abs(F.conv2d(image, ky, padding=1, groups=C)).mean(dim=1, keepdim=True)
+    return gx.abs() + gy.abs()
+
+
+def advanced_uniform_sample_border_points(image, step, pad_num):
+    """arg-max of the gradient magnitude inside every range window [y1-2, y2+2) x [x1-2, x2+2) (:93-113); first maximum in
+    row-major order (torch.argmax); result unique-sorted (:114-117) -> [n, 2] (x, y) int64."""
+    _, _, H, W = image.shape
+    grad = sobel_magnitude(image)
+    pts = []
+    for (x1, y1, x2, y2) in border_ranges(H, W, step, pad_num):
+        mask = torch.zeros_like(grad)
+        mask[:, :, y1 - 2:y2 + 2, x1 - 2:x2 + 2] = 1
+        rg = grad * mask + (-1 * torch.ones_like(grad)) * (1 - mask)
+        idx = int(torch.argmax(rg))
+        pts.append([idx % W, (idx // W) % H])
+    if not pts:
+        return torch.zeros((0, 2), dtype=torch.int64)
+    return torch.unique(torch.tensor(pts), dim=0)
+
+
+# ------------------------------------------------------------------ point pairs (core/inference/utils.py:61-121)
+def get_point_pairs(border_points, flow, flow_limit):
+    B = flow.shape[0]
+    src = border_points.unsqueeze(0).repeat(B, 1, 1)
+    fl = flow[:, :, border_points[:, 1], border_points[:, 0]].permute(0, 2, 1)
+    if flow_limit == -1:
+        flow_limit = (flow.shape[2] + flow.shape[3]) // 2 // 8
+    if flow_limit is not None:
+        a = fl.abs()
+        sel = ((a[:, :, 0] < flow_limit) & (a[:, :, 1] < flow_limit)).unsqueeze(-1).expand_as(fl)
+        src = src[sel].view(B, -1, 2)
+        fl = fl[sel].view(B, -1, 2)
+    return src, src + fl
+
+
+def shift_points(points, width_min, height_min):
+    out = points.clone()
+    out[:, :, 0] = out[:, :, 0] + int(abs(width_min))
+    out[:, :, 1] = out[:, :, 1] + int(abs(height_min))
+    return out
+
+
+def boundary_src_and_tgt(points_src, points_dst, out_height, out_width):
+    B = points_src.shape[0]
+    m = ((points_dst[:, :, 0] >= 0) & (points_dst[:, :, 0] < out_width) & (points_dst[:, :, 1] >= 0) & (points_dst[:, :, 1] < out_height)
+         & (points_src[:, :, 0] >= 0) & (points_src[:, :, 0] < out_width) & (points_src[:, :, 1] >= 0) & (points_src[:, :, 1] < out_height))
+    m = m.unsqueeze(-1).expand_as(points_dst)
+    return points_src[m].view(B, -1, 2), points_dst[m].view(B, -1, 2)
+
+
+def sample_init_points(residual_flow, H_warp, width_min, height_min, grid_h, grid_w, pad_num, get_pt_methods, flow_limit):
+    """tps_pipline.py:247-336 -> (src_points, target_points, points_src, points_dst); the last two shifted onto the canvas."""
+    W, H = residual_flow.shape[-1], residual_flow.shape[-2]
+    left, top = int(abs(width_min)), int(abs(height_min))
+    step = max(H, W) // min(grid_h, grid_w)
+    crop = H_warp[:, :, top:top + H, left:left + W]                      # torchvision crop (:277,:285)
+    src = tgt = None
+    for method in get_pt_methods:
+        bp = advanced_uniform_sample_border_points(crop, step, pad_num)
+        if method == "advanced_uniform_multi":
+            p = step
+            while p <= max(H, W) // 4:
+                bp = torch.cat((bp, advanced_uniform_sample_border_points(crop, step, p)), dim=0)
+                p *= 2
+        elif method != "advanced_uniform":
+            raise NotImplementedError(method)
+        s, t = get_point_pairs(bp, residual_flow, flow_limit)
+        src = s if src is None else torch.cat((src, s), 1)
+        tgt = t if tgt is None else torch.cat((tgt, t), 1)
+    return src, tgt, shift_points(src, width_min, height_min), shift_points(tgt, width_min, height_min)
+
+
+# ------------------------------------------------------------------ TPS (kornia_tps.py:26-176 + kornia's published functions)
+def _pair_square_euclidean(t1, t2):
+    t1_sq = t1.mul(t1).sum(dim=-1, keepdim=True)
+    t2_sq = t2.mul(t2).sum(dim=-1, keepdim=True).transpose(1, 2)
+    return (-2 * t1.matmul(t2.transpose(1, 2)) + t1_sq + t2_sq).clamp(min=0)
+
+
+def _kernel_distance(sq, eps=1e-8):
+    return 0.5 * sq * sq.add(eps).log()
+
+
+def get_tps_transform(points_src, points_dst):
+    """kornia.geometry.transform.get_tps_transform: [K P; P^T 0] [w; a] = [dst; 0], torch.linalg.solve."""
+    B, N = points_src.shape[:2]
+    K = _kernel_distance(_pair_square_euclidean(points_src, points_dst))
+    zero = torch.zeros(B, 3, 3, dtype=points_src.dtype)
+    one = torch.ones(B, N, 1, dtype=points_src.dtype)
+    dest = torch.cat((points_dst, zero[:, :, :2]), 1)
+    P = torch.cat((one, points_src), -1)
+    Pt = torch.cat((P, zero), 1).transpose(1, 2)
+    L = torch.cat((torch.cat((K, P), -1), Pt), 1)
+    w = torch.linalg.solve(L, dest)
+    return w[:, :-3], w[:, -3:]
+
+
+def warp_points_tps(points, centers, kernel_weights, affine_weights):
+    """kornia.geometry.transform.warp_points_tps: a_0 + [a_x a_y] . v + sum_i w_i U(|v - u_i|)."""
+    k = _kernel_distance(_pair_square_euclidean(points, centers))
+    return (k[..., None].mul(kernel_weights[:, None]).sum(-2) + points[..., None].mul(affine_weights[:, None, 1:]).sum(-2)
+            + affine_weights[:, None, 0])
+
+
+def create_meshgrid(h, w):
+    """kornia.utils.create_meshgrid(normalized_coordinates=True): [1,h,w,2] (x, y) in [-1, 1]."""
+    xs = (torch.linspace(0, w - 1, w) / (w - 1) - 0.5) * 2
+    ys = (torch.linspace(0, h - 1, h) / (h - 1) - 0.5) * 2
+    gx, gy = torch.meshgrid(xs, ys, indexing="ij")
+    return torch.stack([gx, gy], -1).permute(1, 0, 2).unsqueeze(0)
+
+
+def warp_image_tps(image, centers, kernel_weights, affine_weights, align_corners=False):
+    B, _, h, w = image.shape
+    coords = create_meshgrid(h, w).reshape(-1, 2).expand(B, -1, -1)
+    warped = warp_points_tps(coords, centers, kernel_weights, affine_weights).view(-1, h, w, 2)
+    return F.grid_sample(image, warped, align_corners=align_corners)
+
+
+def warp_by_tps(H_warp, H_warp_mask, points_src, points_dst, out_height, out_width, kernel_scale=1.0, affine_scale=1.0):
+    """'kornia' branch of tps_pipline.py:362-378: points / (out_width, out_height) through float64 and back."""
+    x = torch.cat((H_warp, H_warp_mask), dim=1)
+    ps, pd = points_src.to(torch.float64), points_dst.to(torch.float64)
+    ps = torch.stack([ps[:, :, 0] / out_width, ps[:, :, 1] / out_height], 2).to(torch.float32)
+    pd = torch.stack([pd[:, :, 0] / out_width, pd[:, :, 1] / out_height], 2).to(torch.float32)
+    kw, aw = get_tps_transform(pd, ps)                       # the reverse transform: dst -> src
+    return warp_image_tps(x, ps, kw * kernel_scale, aw * affine_scale, align_corners=False)
+
+
+# ------------------------------------------------------------------ binary morphology (cv2.erode / cv2.dilate, 11x11 rectangle)
+def _rect_filter(x, k, take_max):
+    p = k // 2
+    if take_max:
+        return F.max_pool2d(F.pad(x, (p, p, p, p), value=float("-inf")), k, stride=1)
+    return -F.max_pool2d(F.pad(-x, (p, p, p, p), value=float("-inf")), k, stride=1)
+
+
+def erode_dilate(x, k=11):
+    return _rect_filter(_rect_filter(x, k, False), k, True)
+
+
+# ------------------------------------------------------------------ pipeline (tps_pipline.py:20-205, inpaint_fn=None)
+def tps_H_warp(inputs, image_limit, cfg):
+    """inputs: dict(output1, mask1, H_warp, H_warp_mask, final_warp, mask2, residual_flow, valid, occlusion_mask,
+    border_points_mask); image_limit: dict(width_min, height_min, out_height, out_width); cfg: TPS_PIPELINE_CONFIG."""
+    out_h, out_w = image_limit["out_height"], image_limit["out_width"]
+    wmin, hmin = image_limit["width_min"], image_limit["height_min"]
+    flow = preprocess(inputs["residual_flow"], inputs["valid"], cfg.do_avg_pooling, cfg.residual_flow_use_forward, cfg.grid_h, cfg.grid_w)
+    src, tgt, ps, pd = sample_init_points(flow, inputs["H_warp"], wmin, hmin, cfg.grid_h, cfg.grid_w, cfg.pad_num,
+                                          cfg.get_pt_methods, cfg.flow_limit)
+    if cfg.use_boundary_limit:
+        ps, pd = boundary_src_and_tgt(ps, pd, out_h, out_w)
+    if cfg.add_corner:
+        corners = torch.tensor([[[0, 0], [0, out_h - 1], [out_w - 1, 0], [out_w - 1, out_h - 1]]]).repeat(ps.shape[0], 1, 1)
+        ps, pd = torch.cat((ps, corners.to(ps.dtype)), 1), torch.cat((pd, corners.to(pd.dtype)), 1)
+    bpm = inputs.get("border_points_mask")
+    if bpm is not None:                                                   # :111-128 (loops over src_points.shape[1] entries)
+        m = bpm[0, 0]
+        keep = [i for i in range(src.shape[1]) if m[int(ps[0, i, 1]), int(ps[0, i, 0])] == 1]
+        keep = torch.tensor(keep, dtype=torch.long)
+        ps, pd = ps[:, keep, :], pd[:, keep, :]
+    both = warp_by_tps(inputs["H_warp"], inputs["H_warp_mask"], ps, pd, out_h, out_w, cfg.kernel_scale, cfg.affine_scale)
+    tps, tmask = both[:, 0:3], both[:, 3:]
+    tmask = (tmask.mean(dim=1, keepdim=True) >= 0.5).float()
+    tmask = 1.0 - erode_dilate(1.0 - tmask, 11)                           # :143-150
+    tps = tps * tmask
+    final_warp, mask1, output1 = inputs["final_warp"], inputs["mask1"], inputs["output1"]
+    fmask = ((final_warp >= 3).float().mean(dim=1, keepdim=True) >= 0.5).float()            # :154-155
+    inv1 = ((1 - mask1).float().mean(dim=1, keepdim=True) >= 0.5).float()
+    mix = final_warp * fmask + tps * (1 - fmask) * inv1
+    mix_mask = fmask + (1 - fmask) * tmask * inv1
+    output2, mask2 = mix * mix_mask, mix_mask
+    blend = ((output1 * mask1 + output2 * mask2) / (mask1 + mask2)).clip(0, 255)
+    blend = torch.nan_to_num(blend, nan=0.0).to(torch.uint8)              # CPU cast of NaN (0/0) is 0
+    res = dict(new_blend_image=blend, tps_output=tps, mix_tps_flow_warp=output2, mix_tps_flow_warp_mask=mask2,
+               points_src=ps, points_dst=pd)
+    if cfg.output2_is_only_tps:
+        output2, mask2 = tps * tmask, tmask
+    res.update(output2=output2, mask2=mask2)
+    return res

@@ -13,7 +13,6 @@
 //   conv_gemm_dma_kernel   Cin % 32 == 0 (the default): global -> LDS DMA ring, VALU-free K loop, optional persistent walk
 //                          over M tiles; tiles 64x64 / 128x64 / 128x32
 //   conv_gemm_kernel       any Cin % 4 == 0 (or scalar gather otherwise): register-staged, [rows][BK+4] padded LDS tiles
-//   conv_gemm_bf16x6_kernel opt-in fp32-grade split-bf16 product (precision = 1)
 //   skinny_gemm_kernel (M <= 8), narrow_conv_kernel (N <= 4), splitk_reduce_kernel
 // and one epilogue (bias, alpha, row-mapped addend, activation, residual / gate / GRU / axpy / fused z|r) shared by all.
 //
@@ -417,6 +416,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    f32x16 tot[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
     const int nkt_all = (K + BK - 1) / BK;
     const int per = (nkt_all + split - 1) / split;
     const int kt0 = kz * per;
@@ -450,7 +456,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const st_gemm_desc d) {
                 }
         }
         if (kt + 1 < nkt) store_tile(buf ^ 1);
+        // K-blocked accumulation, same block boundaries as conv_gemm_dma_kernel (every 8 K steps = 256 k): see there
+        if (((kt - kt0 + 1) & 7) == 0 && kt + 1 < nkt) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    tot[i][jn] = tot[i][jn] + acc[i][jn];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+                }
+        }
         __syncthreads();
+    }
+    if (nkt - kt0 > 8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = acc[i][jn] + tot[i][jn];
     }
 
     gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
@@ -785,163 +808,6 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     if (!PERSIST) gemm_epilogue_store<TM, TN>(d, C, acc, eop, m0, n0, wm, wn, li, lh, split, kz);
 }
 
-// ---------------------------------------------------------------------------------------------
-// fp32 GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand value is split EXACTLY into three bf16 parts
-// (x = x1 + x2 + x3, 8 significant bits each) and the product keeps the six partial products of order <= 2^-16
-// (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2) accumulated in fp32.  The dropped terms are <= 2^-23 relative -- below fp32's
-// own rounding -- so the result is fp32-grade (measured: error vs fp64 at or below the fmaf-chain kernel's), but
-// 16 k cost 6 x 32 cycles of v_mfma_f32_32x32x16_bf16 instead of 8 x 64 cycles of v_mfma_f32_32x32x2_f32.
-// Same staging as the fp32 kernel (fp32 tiles in LDS, so LDS traffic does not grow); the split runs in registers
-// on each wave's fragments, on the VALU, concurrently with other waves' MFMAs.  (A first version that split at
-// LDS-store time into three bf16 planes was LDS-bound: 12 ds_write_b64 + 12 ds_read_b128 per thread and K step.)
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split8(const float4 lo, const float4 hi, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 b1 = (__bf16)x[e];
-        const float r1 = x[e] - (float)b1;
-        const __bf16 b2 = (__bf16)r1;
-        const float r2 = r1 - (float)b2;
-        p1[e] = b1; p2[e] = b2; p3[e] = (__bf16)r2;
-    }
-}
-
-template <int TM, int TN, int BKT>
-__global__ __launch_bounds__(256) void conv_gemm_bf16x6_kernel(const st_gemm_desc d) {
-    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
-    constexpr int LDT = BKT + 4;              // LDS row stride (floats)
-    constexpr int TPR = BKT / 4;              // threads per tile row (one float4 each)
-    constexpr int RPP = 256 / TPR;            // rows staged per pass
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + 2 * BM * LDT;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int split = d.split_k > 1 ? d.split_k : 1;
-    const int bz = split > 1 ? 0 : blockIdx.z;
-    const int kz = split > 1 ? blockIdx.z : 0;
-    const float* __restrict__ X = d.a + (size_t)bz * d.batch_stride_a;
-    const float* __restrict__ Wt = d.w + (size_t)bz * d.batch_stride_w;
-    float* __restrict__ C = d.c + (size_t)bz * d.batch_stride_c;
-    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-    const int nwg = ntm * ntn;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = bid % ntn, tile_m = bid / ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int K = d.K;
-    const int dil_h = d.dh > 1 ? d.dh : 1, dil_w = d.dw > 1 ? d.dw : 1;      // conv dilation (0 / 1 = dense)
-    const int kcol = (tid % TPR) * 4;
-    const int rrow = tid / TPR;
-    constexpr int AP = BM / RPP, BP = BN / RPP;
-    int a_ok[AP], a_iy0[AP], a_ix0[AP], a_b[AP];
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-        const int m = m0 + rrow + RPP * p;
-        a_ok[p] = m < d.M;
-        const int mm = a_ok[p] ? m : 0;
-        const int hw = d.Ho * d.Wo;
-        const int b = mm / hw, r = mm - b * hw;
-        const int oy = r / d.Wo, ox = r - oy * d.Wo;
-        a_b[p] = b; a_iy0[p] = oy * d.sh - d.ph; a_ix0[p] = ox * d.sw - d.pw;
-    }
-    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)d.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, (int)d.w_bytes, 0x00020000);
-    float4 ra[AP], rb[BP];
-    int t_ky = 0, t_kx = 0, t_c = 0, t_kt = -2;
-    auto load_tile = [&](int kt) {
-        const int k = kt * BKT + kcol;
-        if (d.kh * d.kw > 1) {
-            if (t_kt + 1 == kt && d.Cin >= BKT) {
-                t_c += BKT;
-                if (t_c >= d.Cin) { t_c -= d.Cin; if (++t_kx == d.kw) { t_kx = 0; ++t_ky; } }
-            } else {
-                const int kyx = k / d.Cin;
-                t_c = k - kyx * d.Cin; t_ky = kyx / d.kw; t_kx = kyx - t_ky * d.kw;
-            }
-            t_kt = kt;
-        } else { t_c = k; }
-        const bool kin = k < K;
-#pragma unroll
-        for (int p = 0; p < AP; ++p) {
-            const int iy = a_iy0[p] + t_ky * dil_h, ix = a_ix0[p] + t_kx * dil_w;
-            const bool ok = kin && a_ok[p] && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
-            const unsigned off = ok ? (unsigned)(((a_b[p] * d.H + iy) * d.W + ix) * d.ldx + t_c) * 4u : ST_OOB;
-            ra[p] = buf_load16(rsrcA, off);
-        }
-#pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            const int n = n0 + rrow + RPP * p;
-            const bool ok = kin && n < d.N;
-            const unsigned off = ok ? (unsigned)(n * d.ldw + k) * 4u : ST_OOB;
-            rb[p] = buf_load16(rsrcW, off);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < AP; ++p)
-            *reinterpret_cast<float4*>(As + ((size_t)buf * BM + rrow + RPP * p) * LDT + kcol) = ra[p];
-#pragma unroll
-        for (int p = 0; p < BP; ++p)
-            *reinterpret_cast<float4*>(Bs + ((size_t)buf * BN + rrow + RPP * p) * LDT + kcol) = rb[p];
-    };
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nkt_all = (K + BKT - 1) / BKT;
-    const int per = (nkt_all + split - 1) / split;
-    const int kt0 = kz * per;
-    const int nkt = min(nkt_all, kt0 + per);
-    const int li = lane & 31, lh = lane >> 5;
-    if (kt0 < nkt) {
-        load_tile(kt0);
-        store_tile(kt0 & 1);
-    }
-    __syncthreads();
-    for (int kt = kt0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const float* Ab = As + ((size_t)buf * BM + wm * TM * 32 + li) * LDT + 8 * lh;
-        const float* Bb = Bs + ((size_t)buf * BN + wn * TN * 32 + li) * LDT + 8 * lh;
-#pragma unroll
-        for (int c = 0; c < BKT / 16; ++c) {
-            bf16x8 a1[TM], a2[TM], a3[TM], b1[TN], b2[TN], b3[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                split8(*reinterpret_cast<const float4*>(Ab + i * 32 * LDT + 16 * c),
-                       *reinterpret_cast<const float4*>(Ab + i * 32 * LDT + 16 * c + 4), a1[i], a2[i], a3[i]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                split8(*reinterpret_cast<const float4*>(Bb + j * 32 * LDT + 16 * c),
-                       *reinterpret_cast<const float4*>(Bb + j * 32 * LDT + 16 * c + 4), b1[j], b2[j], b3[j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {       // smallest partial products first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b2[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i], b1[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b3[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b1[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b2[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-    gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
-}
-
 // split-K tail: sum the K-slice slabs [split][M][N] in slice order (deterministic) + epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const st_gemm_desc d) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1024,6 +890,8 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const st_gemm_desc d) 
     }
 }
 
+static thread_local int32_t g_last_plan[4] = {-1, 0, 0, 0};
+
 template <int WARPS_M, int WARPS_N, int TM, int TN>
 static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
     constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
@@ -1061,6 +929,7 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
         if (G > ntm) G = ntm;
         auto k = conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        g_last_plan[3] = 1;
         hipLaunchKernelGGL(k, dim3(G * ntn, 1, batch), dim3(256), lds, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;
@@ -1083,6 +952,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
+    if (d.reserved0 != 0) return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // byte extents of one batch slice of A and W for the buffer descriptors (must stay below 2 GiB so the
     // out-of-range sentinel offset is always past num_records)
@@ -1146,11 +1016,13 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
                          (d.batch_stride_a % 4 == 0) && (d.batch_stride_w % 4 == 0);
     const int batch = d.batch > 0 ? d.batch : 1;
     if (d.M <= 8 && d.kh == 1 && d.kw == 1 && aligned && batch == 1 && d.epi == ST_EPI_STORE && !d.aux0 && d.H * d.W == d.M) {
+        g_last_plan[0] = 0; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 0;
         hipLaunchKernelGGL(skinny_gemm_kernel<8>, dim3((d.N * 64 + 255) / 256), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;
     }
     if (d.N <= 4 && aligned && batch == 1 && d.epi != ST_EPI_ZR && d.M >= 1024 && d.tile_cfg == 0 && d.split_k <= 1) {
+        g_last_plan[0] = 1; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 0;
         hipLaunchKernelGGL(narrow_conv_kernel<4>, dim3((d.M + 3) / 4), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;
@@ -1166,7 +1038,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         // mid-size shape of this path (more resident workgroups); 128-wide tiles stay selectable through tile_cfg.
         const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M;
         const bool stream128 = d.K == 128 && plain && d.N > 32 && nwg(64, 64) > 512;      // persistent walk hides the 4-step K loop
-        const bool dma = dma_ok && (d.K >= 256 || stream128) && d.precision == 0;
+        const bool dma = dma_ok && (d.K >= 256 || stream128);
         if (d.N <= 32) cfg = dma ? 14 : 4;
         else cfg = dma ? 13 : 3;
     }
@@ -1195,24 +1067,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     }
     if (split > 1 && (batch != 1 || !d.workspace || (int64_t)split * d.M * d.N > d.workspace_floats)) return ST_EINVAL;
     d.split_k = split;
-    if (d.precision == 1 && aligned && (cfg == 3 || cfg == 2 || cfg == 1)) {     // fp32-grade split-bf16 kernel
-        auto launch = [&](auto kern, int bm, int bn) {
-            const int ntm = (d.M + bm - 1) / bm, ntn = (d.N + bn - 1) / bn;
-            dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : batch);
-            const int bkt = d.K >= 256 ? 64 : 32;
-            const size_t lds = (size_t)2 * (bm + bn) * (bkt + 4) * sizeof(float);
-            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
-        };
-        const bool deep = d.K >= 256;        // 64-deep K steps halve the barriers per FLOP once K is long enough
-        if (cfg == 3) { if (deep) launch(conv_gemm_bf16x6_kernel<1, 1, 64>, 64, 64); else launch(conv_gemm_bf16x6_kernel<1, 1, 32>, 64, 64); }
-        else if (cfg == 2) { if (deep) launch(conv_gemm_bf16x6_kernel<2, 1, 64>, 128, 64); else launch(conv_gemm_bf16x6_kernel<2, 1, 32>, 128, 64); }
-        else { if (deep) launch(conv_gemm_bf16x6_kernel<2, 2, 64>, 128, 128); else launch(conv_gemm_bf16x6_kernel<2, 2, 32>, 128, 128); }
-        if (d.split_k > 1)
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(((size_t)d.M * d.N + 255) / 256), dim3(256), 0, s, d);
-        ST_CHECK_LAUNCH();
-        return ST_OK;
-    }
+    g_last_plan[0] = cfg > 10 ? 3 : 2; g_last_plan[1] = cfg; g_last_plan[2] = split; g_last_plan[3] = 0;
     if (cfg == 12) return launch_dma<2, 2, 2, 1, 4>(d, s);
     if (cfg == 13) return launch_dma<2, 2, 1, 1, 4>(d, s);
     if (cfg == 14) return launch_dma<4, 1, 1, 1, 4>(d, s);
@@ -1238,6 +1093,12 @@ extern "C" int st_corr_volume(const float* f1, const float* f2, float* vol, int3
     d.batch = B; d.batch_stride_a = (int64_t)N1 * C; d.batch_stride_w = (int64_t)N2 * C;
     d.batch_stride_c = (int64_t)N1 * N2;
     return st_conv_gemm(&d, stream);
+}
+
+extern "C" int st_gemm_last_plan(int32_t* plan4) {
+    if (!plan4) return ST_EINVAL;
+    for (int i = 0; i < 4; ++i) plan4[i] = g_last_plan[i];
+    return ST_OK;
 }
 
 // ABI self-check for bindings: size of st_gemm_desc as this library was compiled.

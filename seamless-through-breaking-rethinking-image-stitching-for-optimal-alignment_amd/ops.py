@@ -38,10 +38,6 @@ def _ld(t):
     return t.stride(0)
 
 
-# 0: exact-fp32 MFMA kernel; 1: fp32-grade bf16x6 split kernel where its preconditions hold (see gemm.hip)
-import os as _os
-GEMM_PRECISION = int(_os.environ.get("STITCH_GEMM_PRECISION", "0"))
-
 _WS = {}
 _WS_OVERRIDE = []
 
@@ -78,7 +74,7 @@ class workspace_scope:
 
 
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
-              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, dil=(1, 1), M=None, tile=0, split_k=0, out2=None, precision=None):
+              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, dil=(1, 1), M=None, tile=0, split_k=0, out2=None):
     """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
 
     x: 2-D view [rows, Cin] of a channels-last activation; geom=(B,H,W,kh,kw,sh,sw,ph,pw) or None (1x1).
@@ -115,7 +111,6 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     d.batch_stride_aux1 = bsx1
     d.dh, d.dw = dil
     d.tile_cfg = tile
-    d.precision = GEMM_PRECISION if precision is None else precision
     d.split_k = split_k
     if out2 is not None:
         d.c2, d.ldc2 = out2.data_ptr(), _ld(out2)

@@ -142,28 +142,6 @@ def test_patch_conv1_direct(ops):
     assert (from_rows(out, 5, 8, 8) - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("tile", [0, 2, 1])
-def test_gemm_bf16x6_split_precision_is_fp32_grade(ops, tile):
-    """precision=1: exact 3-way bf16 split, six partial products on the bf16 MFMA, fp32 accumulate -- error vs
-    fp64 must stay at the level of the exact-fp32 kernel (it is an opt-in, the default path is precision=0)."""
-    M, N, K = 3000, 200, 1920
-    a, w = torch.randn(M, K, generator=g(90)), torch.randn(N, K, generator=g(91)) / K ** 0.5
-    bias = torch.randn(N, generator=g(92))
-    ref = F.linear(a.double(), w.double(), bias.double())
-    ad, wd = dev(a), dev(w)
-    o0, o1 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
-    ops.conv_gemm(ad, wd, o0, bias=dev(bias), precision=0)
-    ops.conv_gemm(ad, wd, o1, bias=dev(bias), precision=1, tile=tile)
-    e0, e1 = (o0.cpu().double() - ref).abs().max().item(), (o1.cpu().double() - ref).abs().max().item()
-    assert e1 < 2e-5 and e1 < 2.0 * e0 + 1e-6, (e0, e1)
-    x = torch.randn(2, 64, 12, 16, generator=g(93))
-    cw = torch.randn(96, 64, 3, 3, generator=g(94)) / 24
-    refc = F.conv2d(x, cw, padding=1)
-    out = torch.empty(2 * 12 * 16, 96, device="cuda")
-    ops.conv_gemm(nhwc(x), pack_conv_w(cw), out, geom=(2, 12, 16, 3, 3, 1, 1, 1, 1), precision=1, split_k=3)
-    assert (from_rows(out, 2, 12, 16) - refc).abs().max() < 2e-5
-
-
 def test_corr_volume(ops):
     f1, f2 = torch.randn(2, 256, 16, 16, generator=g(13)), torch.randn(2, 256, 16, 16, generator=g(14))
     ref = nets.corr_volume(f1, f2)
@@ -414,47 +392,63 @@ def test_range_map_occlusion_open(ops, golden_ops):
 
 
 def test_tps(ops, golden_ops):
+    """UDIS2 TPS transformer (torch_tps_transform.py:7-190) against the oracle AND the reference golden `tps_out`.
+    The contraction T @ grid is the same ascending-k fused chain torch.matmul uses for this shape (measured bit for
+    bit); what is left differs only through logf (torch: SLEEF u10, here: ocml, both <= 1 ulp) inside r^2 log r^2 and
+    through the fp64 solve's last bits before the cast to fp32, so sample indices agree except where a coordinate
+    lands within ~1e-5 px of an integer."""
     U, src, tgt = T(golden_ops["tps_U"]), T(golden_ops["tps_source"]), T(golden_ops["tps_target"])
-    out, Tm = ops.tps_transform(dev(U), dev(src), dev(tgt), (24, 28))
+    out, Tm, idx = ops.tps_transform(dev(U), dev(src), dev(tgt), (24, 28), want_idx=True)
     ref_out, ref_T = geom.tps_transformer(U, src, tgt, (24, 28))
-    assert (Tm.cpu() - ref_T).abs().max() < 1e-4 * max(1.0, ref_T.abs().max().item())
-    d = (out.cpu() - ref_out).abs()
-    # K=172 fp32 contraction with cancellation: sample positions agree to ~1e-4 px, values on a 0..255
-    # noise image to a few 1e-2 (the reference itself differs from the oracle by this much across hosts)
-    assert np.percentile(d.numpy(), 99) < 5e-2 and d.mean() < 1e-2 and d.max() < 5.0, (np.percentile(d.numpy(), 99), d.mean(), d.max())
+    relT = (Tm.cpu() - ref_T).abs().max().item() / max(1.0, ref_T.abs().max().item())
+    assert relT < 1e-4, relT                     # fp64 solve of a 172x172 system whose entries were rounded to fp32 first
+    # the oracle's own sample indices from its T and grid (same _interpolate arithmetic as the homography transformer)
+    ref_idx = geom.tps_indices(src, ref_T, U.shape[-2:], (24, 28))
+    mism = (idx.cpu() != ref_idx).any(-1)
+    d = (out.cpu() - T(golden_ops["tps_out"])).abs()
+    same = ~mism[:, None].expand_as(d)
+    print(f"[tps] T rel {relT:.2e}; idx mismatches {int(mism.sum())} / {mism.numel()}; |out - golden| max {d.max():.3e} "
+          f"(where idx agree: {d[same].max():.3e})")
+    assert mism.float().mean() < 5e-3, int(mism.sum())
+    assert d[same].max() < 2e-2 and np.percentile(d.numpy(), 99) < 2e-2, (d[same].max(), np.percentile(d.numpy(), 99))
 
 
 def test_blend_and_eval_finish(ops):
+    """Mask algebra + uint8 blend (flowHomoAdpater.py:339-360): every intermediate is one fp32 rounding per torch op in
+    the reference, and the kernel keeps exactly those roundings (no contraction): outputs are BIT-EXACT, including the
+    uint8 bytes, for binary masks and for the fractional masks the bilinear warps really produce."""
     gg = g(44)
-    h, w = 37, 53
-    homo1, homo2 = torch.rand(1, 6, h, w, generator=gg) * 255, torch.rand(1, 6, h, w, generator=gg) * 255
-    for t in (homo1, homo2):
-        t[:, 3:] = (t[:, 3:] > 100).float()
-    fin = torch.rand(1, 6, h, w, generator=gg) * 255
-    fin[:, 3:] = (fin[:, 3:] > 60).float()
-    occ = (torch.rand(1, 1, h, w, generator=gg) > 0.3).float()
-    f = fin * occ
-    o1, m1 = homo1[:, :3], homo1[:, 3:]
-    o2, m2 = f[:, :3], f[:, 3:]
-    nov = 1 - m1
-    o2r = homo2[:, :3] * (1 - m2) * nov + o2 * m2
-    m2r = homo2[:, 3:] * (1 - m2) * nov + m2 * m2
-    bl = torch.nan_to_num(((o1 * m1 + o2r * m2r) / (m1 + m2r)).clip(0, 255), nan=0.0).to(torch.uint8)
-    find = dev(fin)
-    go2, gm1, gm2, gbl = ops.blend(dev(homo1), dev(homo2), find, dev(occ))
-    assert (find.cpu() - f).abs().max() == 0
-    assert (go2.cpu() - o2r).abs().max() < 1e-4
-    assert (gbl.cpu().int() - bl.int()).abs().max() <= 1 and (gbl.cpu() != bl).float().mean() < 1e-3
-    assert (gm1.cpu() - m1.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1)).abs().max() < 1e-6
-    assert (gm2.cpu() - m2r.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1)).abs().max() < 1e-6
+    h, w = 67, 131
+    for fractional in (False, True):
+        homo1, homo2 = torch.rand(1, 6, h, w, generator=gg) * 255, torch.rand(1, 6, h, w, generator=gg) * 255
+        fin = torch.rand(1, 6, h, w, generator=gg) * 255
+        for t, thr in ((homo1, 100), (homo2, 100), (fin, 60)):
+            t[:, 3:] = torch.rand(1, 1, h, w, generator=gg).expand(-1, 3, -1, -1) if fractional else (t[:, 3:] > thr).float()
+        if fractional:                                           # zones of exact 0 / 1 as in real canvases (0/0 -> NaN -> 0)
+            homo1[:, 3:, :20] = 0; homo2[:, 3:, :30] = 0; fin[:, 3:, :25] = 0; homo1[:, 3:, 40:] = 1
+        occ = (torch.rand(1, 1, h, w, generator=gg) > 0.3).float()
+        f = fin * occ
+        o1, m1 = homo1[:, :3], homo1[:, 3:]
+        o2, m2 = f[:, :3], f[:, 3:]
+        nov = 1 - m1
+        o2r = homo2[:, :3] * (1 - m2) * nov + o2 * m2                              # oracle/adapter.py:99-100
+        m2r = homo2[:, 3:] * (1 - m2) * nov + m2 * m2
+        bl = torch.nan_to_num(((o1 * m1 + o2r * m2r) / (m1 + m2r)).clip(0, 255), nan=0.0).to(torch.uint8)
+        find = dev(fin)
+        go2, gm1, gm2, gbl = ops.blend(dev(homo1), dev(homo2), find, dev(occ))
+        assert torch.equal(find.cpu(), f)
+        assert torch.equal(go2.cpu(), o2r)
+        assert torch.equal(gbl.cpu(), bl), (int((gbl.cpu() != bl).sum()), fractional)
+        assert torch.equal(gm1.cpu(), m1.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1))
+        assert torch.equal(gm2.cpu(), m2r.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1))
     fin6 = torch.rand(2, 6, h, w, generator=gg)
     occ2 = (torch.rand(2, 1, h, w, generator=gg) > 0.5).float()
     fd = dev(fin6)
     ov = ops.eval_finish(fd, dev(occ2))
-    assert torch.equal(ov.cpu(), (fin6[:, 3:6].mean(1) < 0.9).float()) or (ov.cpu() != (fin6[:, 3:6].mean(1) < 0.9).float()).sum() <= 1
-    assert (fd.cpu() - fin6 * occ2).abs().max() == 0
+    assert torch.equal(ov.cpu(), (fin6[:, 3:6].mean(1) < 0.9).float())
+    assert torch.equal(fd.cpu(), fin6 * occ2)
     mt = ops.mean_threshold(dev(fin6[:, 3:6].contiguous()), 0.5)
-    assert (mt.cpu() != (fin6[:, 3:6].mean(1, keepdim=True) > 0.5).float()).sum() <= 1
+    assert torch.equal(mt.cpu(), (fin6[:, 3:6].mean(1, keepdim=True) > 0.5).float())
 
 
 def test_decoder_token_chain_fused(ops, seeded_sd):

@@ -1,0 +1,155 @@
+"""Per-shape roofline table of the fp32-MFMA GEMM family: one row per distinct st_conv_gemm launch shape of ONE step
+(FlowHomoAdpater.forward(type="test_eval"), 512x512, batch 1) -> profiles/r2_gemm_shapes.csv.
+
+    python tools/gemm_shapes_csv.py OUT.csv [--launches LAUNCHES.json]           # timing pass (HIP events, observer hook)
+    python tools/gemm_shapes_csv.py OUT.csv --join LAUNCHES.json FETCH.csv WRITE.csv   # add PMC bytes per shape (no GPU)
+
+Timing pass: two warm-up steps, then one eager step with a HIP-event pair around every launch (library observer,
+`st_gemm_last_plan` tells which kernel / tile / split-K / persistent walk the library chose).  With --launches the ordered
+launch list is saved so that a later `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` run OF THE SAME
+COMMAND (one counter per pass, MI355X_MICROARCH.md) can be joined: GEMM-family dispatches appear in the same order in
+rocprofv3's counter_collection.csv (split-K launches are followed by their reducer, which is counted with them).
+Columns: algorithmic bytes = A (input rows x Cin, each element once) + W + C, fp32; PMC bytes with the gfx950 corrections
+(FETCH_SIZE KiB x 2, WRITE_SIZE KiB x 1)."""
+import collections
+import csv
+import ctypes as C
+import json
+import re
+import sys
+
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+
+FAMILY = {0: "skinny_gemm_kernel", 1: "narrow_conv_kernel", 2: "conv_gemm_kernel", 3: "conv_gemm_dma_kernel"}
+PEAK = 157.3
+
+
+def shape_key(r):
+    return (r["M"], r["N"], r["K"], r["conv"], r["batch"], r["kernel"], r["tile"], r["split_k"], r["persist"], r["epi"])
+
+
+def timing_pass(out_csv, launches_json=None, profile_only=False):
+    import torch
+    import stitch_amd
+    from stitch_amd.data import structured_pair
+    lib, GemmDesc = stitch_amd._lib.lib, stitch_amd._lib.GemmDesc
+    cfg, _ = stitch_amd.load_inference_config("all_img1_with_inpaint_g12_transRef")
+    torch.manual_seed(1234)
+    model = stitch_amd.build_model(cfg).cuda().eval()
+    a, b = (t.cuda() for t in structured_pair(512, 512, seed=7))
+    for _ in range(2):
+        model(a, b, type="test_eval")
+    torch.cuda.synchronize()
+    rec, open_ev = [], []
+    plan = (C.c_int32 * 4)()
+
+    @C.CFUNCTYPE(None, C.POINTER(GemmDesc), C.c_void_p, C.c_int32, C.c_void_p)
+    def observer(desc, stream, phase, user):
+        ev = None
+        if not profile_only:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream())
+        if phase == 0:
+            open_ev.append(ev)
+            return
+        d = desc.contents
+        lib.st_gemm_last_plan(plan)
+        nb = max(1, d.batch)
+        conv = d.kh * d.kw > 1 or d.sh > 1
+        a_rows = (d.M // max(1, d.Ho * d.Wo)) * d.H * d.W if conv else d.M
+        rec.append(dict(M=d.M, N=d.N, K=d.K, conv=f"{d.kh}x{d.kw}s{d.sh}" + (f"d{d.dh}" if d.dh > 1 else ""), batch=nb,
+                        kernel=FAMILY.get(plan[0], "?"), tile=plan[1], split_k=plan[2], persist=plan[3], epi=d.epi,
+                        flops=2.0 * d.M * d.N * d.K * nb, alg_bytes=4.0 * nb * (a_rows * d.Cin + d.N * d.K + d.M * d.N),
+                        ev=(open_ev.pop(), ev)))
+
+    lib.st_set_gemm_observer(C.cast(observer, C.c_void_p), None)
+    try:
+        model(a, b, type="test_eval")
+        torch.cuda.synchronize()
+    finally:
+        lib.st_set_gemm_observer(None, None)
+    for r in rec:
+        e0, e1 = r.pop("ev")
+        r["us"] = 1e3 * e0.elapsed_time(e1) if e0 is not None else 0.0
+    if launches_json:
+        json.dump(rec, open(launches_json, "w"))
+    if not profile_only:
+        write_csv(out_csv, rec)
+
+
+def write_csv(out_csv, rec):
+    agg = collections.OrderedDict()
+    for r in rec:
+        g = agg.setdefault(shape_key(r), dict(launches=0, us=0.0, flops=0.0, alg=0.0, fetch=0.0, write=0.0, pmc=0))
+        g["launches"] += 1
+        g["us"] += r["us"]
+        g["flops"] += r["flops"]
+        g["alg"] += r["alg_bytes"]
+        if "fetch_bytes" in r:
+            g["fetch"] += r["fetch_bytes"]
+            g["write"] += r["write_bytes"]
+            g["pmc"] += 1
+    tot_us = sum(g["us"] for g in agg.values())
+    with open(out_csv, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["M", "N", "K", "conv", "batch", "kernel", "tile_cfg", "split_k", "persistent", "epilogue", "launches_per_step",
+                    "us_per_launch", "ms_per_step", "share_of_gemm_time", "TFLOP/s", "frac_of_fp32_mfma_peak", "GFLOP_per_launch",
+                    "algorithmic_MB_per_launch", "pmc_fetch_MB_per_launch", "pmc_write_MB_per_launch", "pmc_over_algorithmic",
+                    "HBM_GB/s_algorithmic"])
+        for key, g in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):
+            n = g["launches"]
+            tf = g["flops"] / g["us"] / 1e6 if g["us"] else 0.0
+            pmc = (g["fetch"] + g["write"]) if g["pmc"] else None
+            w.writerow(list(key[:10]) + [n, f"{g['us'] / n:.1f}", f"{g['us'] / 1e3:.3f}", f"{g['us'] / tot_us:.4f}" if tot_us else "",
+                                        f"{tf:.1f}", f"{tf / PEAK:.3f}", f"{g['flops'] / n / 1e9:.3f}", f"{g['alg'] / n / 1e6:.2f}",
+                                        "" if pmc is None else f"{g['fetch'] / n / 1e6:.2f}", "" if pmc is None else f"{g['write'] / n / 1e6:.2f}",
+                                        "" if pmc is None else f"{pmc / g['alg']:.2f}", f"{g['alg'] / g['us'] / 1e3:.0f}" if g["us"] else ""])
+        tf = sum(g["flops"] for g in agg.values()) / tot_us / 1e6 if tot_us else 0.0
+        w.writerow(["TOTAL", "", "", "", "", "", "", "", "", "", sum(g["launches"] for g in agg.values()), "", f"{tot_us / 1e3:.3f}", "1.0",
+                    f"{tf:.1f}", f"{tf / PEAK:.3f}", "", f"{sum(g['alg'] for g in agg.values()) / 1e6:.1f}",
+                    f"{sum(g['fetch'] for g in agg.values()) / 1e6:.1f}", f"{sum(g['write'] for g in agg.values()) / 1e6:.1f}", "", ""])
+    print(open(out_csv).read())
+
+
+def join(out_csv, launches_json, fetch_csv, write_csv_path):
+    rec = json.load(open(launches_json))
+
+    def gemm_rows(path):
+        rows = []
+        for r in csv.DictReader(open(path)):
+            k = re.sub(r"\(.*", "", r["Kernel_Name"]).strip()
+            if any(s in k for s in ("conv_gemm", "skinny_gemm", "narrow_conv", "splitk_reduce")):
+                rows.append((int(r.get("Dispatch_Id", len(rows))), k, float(r["Counter_Value"])))
+        rows.sort()
+        return rows
+    F, Wr = gemm_rows(fetch_csv), gemm_rows(write_csv_path)
+    per_step = len(rec) + sum(1 for r in rec if r["split_k"] > 1)
+    # the profiled command runs 2 warm-up steps + the instrumented one: keep the dispatches of the LAST step
+    for rows in (F, Wr):
+        assert len(rows) >= per_step, (len(rows), per_step)          # the first warm-up step also builds cached constant tables
+    F, Wr = F[-per_step:], Wr[-per_step:]
+    i = 0
+    for r in rec:
+        n = 2 if r["split_k"] > 1 else 1
+        assert "splitk_reduce" not in F[i][1] and (n == 1 or "splitk_reduce" in F[i + 1][1]), (i, F[i], r)
+        r["fetch_bytes"] = sum(v for _, _, v in F[i:i + n]) * 1024 * 2          # gfx950: FETCH_SIZE tallies wide reads at half size
+        r["write_bytes"] = sum(v for _, _, v in Wr[i:i + n]) * 1024
+        i += n
+    write_csv(out_csv, rec)
+    tot = dict(fetch_bytes_per_step=sum(r["fetch_bytes"] for r in rec), write_bytes_per_step=sum(r["write_bytes"] for r in rec),
+               algorithmic_bytes_per_step=sum(r["alg_bytes"] for r in rec), launches_per_step=len(rec),
+               kernel="conv_gemm_dma_kernel + conv_gemm_kernel + skinny/narrow variants + split-K reducers (all st_conv_gemm launches of one step)",
+               corrections="FETCH_SIZE KiB x2 (MI355X_MICROARCH.md HBM section), WRITE_SIZE KiB x1",
+               source="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/gemm_shapes_csv.py x.csv --profile-only")
+    json.dump(tot, open(out_csv.replace("gemm_shapes.csv", "traffic.json"), "w"), indent=1)
+    print(json.dumps(tot, indent=1))
+
+
+if __name__ == "__main__":
+    out = sys.argv[1]
+    if "--join" in sys.argv:
+        i = sys.argv.index("--join")
+        join(out, *sys.argv[i + 1:i + 4])
+    else:
+        lj = sys.argv[sys.argv.index("--launches") + 1] if "--launches" in sys.argv else None
+        timing_pass(out, lj, profile_only="--profile-only" in sys.argv)
