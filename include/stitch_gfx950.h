@@ -252,6 +252,45 @@ int st_compose_blend(const float* warp1, const float* warp2, const float* mask1,
 /* out.py:284 normalize_fn: clip(0,255)/127.5 - 1.                                                          */
 int st_compose_normalize(const float* x, float* out, int64_t n, void* stream);
 
+/* ---- TPS post-pipeline (core/inference/*, in-tree "kornia" back-end, no inpainter) ---------------- */
+/* preprocess (tps_pipline.py:213-244): zero-padded k x k mean of flow [B,C,H,W] (row-major window sum / k^2), optional
+ * negation (residual_flow_use_forward = False), optional * valid [B,1,H,W].                                             */
+int st_flow_boxavg(const float* flow, const float* valid, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                   int32_t k, int32_t negate, void* stream);
+/* advanced_uniform_sample_border_points (sample_point_methods.py:70-90): image [C,H,W] -> grad [H,W] =
+ * mean_c |Sobel_x| + mean_c |Sobel_y| (zero padding).                                                                    */
+int st_sobel_magnitude(const float* img, float* grad, int32_t C, int32_t H, int32_t W, void* stream);
+/* sample_point_methods.py:93-113: for every range (x1,y1,x2,y2) the first arg-max of grad over rows [y1-2, y2+2) x
+ * cols [x1-2, x2+2) -> flat index y*W + x.                                                                               */
+int st_range_argmax(const float* grad, const int32_t* ranges, int32_t* out_flat_idx, int32_t n_ranges, int32_t H,
+                    int32_t W, void* stream);
+/* get_point_pairs flow lookup (core/inference/utils.py:61-68) / border_points_mask filter (tps_pipline.py:111-128):
+ * out[i, p] = planes[p, y_i, x_i] for integer points (x, y).                                                             */
+int st_gather_points(const float* planes, const int32_t* points_xy, float* out, int32_t n, int32_t P, int32_t H,
+                     int32_t W, void* stream);
+/* TPS fit f(sites_i) = values_i, f(v) = a0 + [ax ay].v + sum_j w_j U(|v - centers_j|) -> kernel_w [n,2], affine_w [3,2];
+ * work_f64: (n+3)*(n+5) doubles.  mode 0 = kornia get_tps_transform(points_src = sites, points_dst = centers = values) as
+ * called by warp_by_tps (tps_pipline.py:362-378, kornia_tps.py:47-112): normalised points, U = 0.5 d2 log(d2 + 1e-8);
+ * mode 1 = pixel-unit r^2 log r^2 spline with centers = sites (OpenCV ThinPlateSplineShapeTransformer's formulation,
+ * opencv_tps.py:8-18).                                                                                                  */
+int st_tps2_solve(const float* sites, const float* centers, const float* values, void* work_f64, float* kernel_w,
+                  float* affine_w, int32_t n, int32_t mode, void* stream);
+/* warp_image_tps (kornia_tps.py:114-176): img [C,H,W] -> out [C,H,W]; centers [n,2]; grid_sample(bilinear, zeros).       */
+int st_tps2_warp(const float* img, const float* centers, const float* kernel_w, const float* affine_w, float* out,
+                 int32_t C, int32_t H, int32_t W, int32_t n, float kernel_scale, float affine_scale,
+                 int32_t align_corners, int32_t mode, void* stream);
+/* cv2.erode / cv2.dilate with a k x k rectangle (tps_pipline.py:143-148) = two 1-D passes of this filter (axis 0: x,
+ * axis 1: y), window clipped to the image; in != out.                                                                    */
+int st_minmax_filter(const float* in, float* out, int32_t planes, int32_t H, int32_t W, int32_t k, int32_t is_max,
+                     int32_t axis, void* stream);
+/* tps_pipline.py:139-141: inv [h,w] = 1 - (mean_c(warped_mask [C,h,w]) >= 0.5).                                          */
+int st_tps_mask_inv(const float* warped_mask, float* inv, int32_t C, int32_t h, int32_t w, void* stream);
+/* tps_pipline.py:150-176 with inv_clean = dilate(erode(inv)): tps3 *= tmask (in place), tmask [h,w], mix3 = output2 of
+ * the flow/TPS mix, mixmask [h,w], blend3 uint8 [3,h,w] = clip((output1*mask1 + mix*mixmask) / (mask1 + mixmask)).      */
+int st_tps_mix_blend(float* tps3, const float* inv_clean, const float* final_warp3, const float* output1_3,
+                     const float* mask1_3, float* tmask, float* mix3, float* mixmask, uint8_t* blend3, int32_t h,
+                     int32_t w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,32 @@ import torch
 import torch.nn.functional as F
 
 
+# ------------------------------------------------------------------ synthetic inputs of the fixtures / tests
+def synthetic_case(seed, ih, iw, wmin, hmin, out_h, out_w):
+    """A `test_out`-shaped input set: canvases [1,3,out_h,out_w], flow at image size, binary masks."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(out_h).float(), torch.arange(out_w).float(), indexing="ij")
+    tex = (torch.rand(1, 3, out_h // 8 + 2, out_w // 8 + 2, generator=g) * 255)
+    tex = torch.nn.functional.interpolate(tex, size=(out_h, out_w), mode="bilinear", align_corners=False)
+    tex = (tex + 20 * torch.sin(xx / 7.0) * torch.cos(yy / 5.0)).clip(0, 255)
+    left, top = abs(wmin), abs(hmin)
+    in_img = ((xx >= left + 6) & (xx < left + iw - 9) & (yy >= top + 4) & (yy < top + ih - 7)).float()
+    H_warp_mask = in_img[None, None].repeat(1, 3, 1, 1)
+    H_warp = tex * H_warp_mask
+    mask1 = ((xx >= left) & (xx < left + iw) & (yy >= top) & (yy < top + ih)).float()[None, None].repeat(1, 3, 1, 1)
+    mask1[:, :, :, left + iw // 2:] = 0                                   # image 1 covers the left half
+    output1 = (255 - tex) * mask1
+    fy, fx = torch.meshgrid(torch.arange(ih).float(), torch.arange(iw).float(), indexing="ij")
+    flow = torch.stack([4 * torch.sin(fx / 40.0) + 2 * torch.cos(fy / 23.0), 3 * torch.cos(fx / 31.0) - 2 * torch.sin(fy / 17.0)])[None]
+    flow = flow + 0.5 * torch.randn(1, 2, ih, iw, generator=g)
+    occ = (torch.rand(1, 1, out_h, out_w, generator=g) > 0.15).float()
+    final_warp = tex.roll(3, -1) * H_warp_mask
+    final_warp[:, :, : top + 10] = 0
+    return dict(output1=output1, mask1=mask1, H_warp=H_warp, H_warp_mask=H_warp_mask, final_warp=final_warp,
+                mask2=H_warp_mask.clone(), residual_flow=flow, valid=None, occlusion_mask=occ, border_points_mask=occ)
+
+
+
 # ------------------------------------------------------------------ preprocess (tps_pipline.py:213-244)
 def preprocess(residual_flow, valid, do_avg_pooling, residual_flow_use_forward, grid_h, grid_w):
     if do_avg_pooling:

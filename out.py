@@ -1,13 +1,15 @@
-"""Inference + save harness of the stitching path (re-statement of the reference's out.py:15-54,106-146,158-275,
-SURVEY.md section 8 f-1) on the MI355X package.
+"""Inference + save harness of the stitching path (re-statement of the reference's out.py:15-54,106-146,158-312,
+SURVEY.md section 8 f-1 / f-3) on the MI355X package.
 
     python out.py --data_root_path ./demo/ --inf_cfg all_img1_with_inpaint_g12_transRef [--ckpt_path CKPT]
 
 Same flags, `demo.txt` pair list (one directory per line holding input1.jpg / input2.jpg), RGB-float loading and
-result-directory naming as the reference.  The forward (`type="test_out"`) runs on the HIP kernels; its images are
-written as JPEGs.  The TPS / inpainting post-pipeline (core/inference/**, section 8 f-3) is out of scope this round,
-so `ave_fusion.jpg` holds the forward's own `blend_image` (the reference writes the post-TPS blend there) and the
-composition stage (out.py:277-312, section 8 f-4; `cfg.use_composition`) runs on the forward's canvases."""
+result-directory naming as the reference.  The forward (`type="test_out"`) and the TPS post-pipeline
+(core/inference/tps_pipline.py, `stitch_amd.tps_pipeline`) run on the HIP kernels; the composition stage (out.py:277-312,
+`cfg.use_composition`) runs on the post-TPS canvases.  Differences from the reference's files, all because the inpainters
+(TransRef / diffusion, fetched weights + third-party CUDA ops) are out of scope: `warp2.jpg`, `mask2.jpg`, `ave_fusion.jpg`,
+`composition.jpg`, `learned_mask*.jpg` hold the post-TPS result BEFORE inpainting; with the shipped `tps_method="opencv"` the
+spline is this package's own pixel-unit TPS (OpenCV is not installable here: unpinned against OpenCV)."""
 from __future__ import annotations
 
 import argparse
@@ -73,7 +75,9 @@ def to_pillow(t):
 
 @torch.no_grad()
 def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_model=None):
-    """out.py:158-312 up to the saves (without the TPS / inpainting post-pipeline)."""
+    """out.py:158-312: forward (`test_out`), TPS post-pipeline, saves, composition.  The inpainting step of the reference
+    (mix_fn / inpainter, out.py:235-236) is out of scope: `warp2.jpg`, `mask2.jpg`, `ave_fusion.jpg` and the composition
+    inputs are the post-TPS images BEFORE inpainting (the reference writes the inpainted ones)."""
     from PIL import Image
     path = data_dict["DATA_PATH"]
     name = os.path.basename(os.path.normpath(path))
@@ -84,17 +88,32 @@ def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_m
     if getattr(cfg, "swap_image", False):
         image1, image2 = image2, image1
     out = warp_model(image1.cuda(), image2.cuda(), type="test_out", pad_mode=cfg.pad_mode)
+    # ---- TPS post-pipeline (out.py:218-258, core/inference/tps_pipline.py:20-205) on the GPU, inpainting excluded
+    import stitch_amd
+    tpc = cfg.TPS_PIPELINE_CONFIG
+    fb = getattr(cfg, "use_fb_consistency_mask", False)
+    valid = out["origin_occlusion_mask"] if (fb and tpc.use_valid_on_flow) else None                      # out.py:219-222
+    border_points_mask = None
+    if fb and tpc.use_border_points_mask:                                                                 # out.py:224-232
+        border_points_mask = out["occlusion_mask"] if tpc.use_occ_filter else (out["H_warp_mask"].mean(dim=1, keepdim=True) > 0.5).float()
+    inputs = dict(output1=out["output1"], mask1=out["mask1"], H_warp=out["H_warp"], H_warp_mask=out["H_warp_mask"],
+                  final_warp=out["final_warp"], mask2=out["mask2"], residual_flow=out["residual_flow"], valid=valid,
+                  occlusion_mask=out["occlusion_mask"], border_points_mask=border_points_mask)
+    limit = dict(width_min=out["width_min"], height_min=out["height_min"], out_height=out["out_height"], out_width=out["out_width"])
+    new = stitch_amd.tps_pipeline.tps_H_warp(inputs, limit, tpc, inpaint_fn=None)
+    out = dict(out, forward_output2=out["output2"], forward_mask2=out["mask2"], forward_blend_image=out["blend_image"],
+               new_blend_image=new["new_blend_image"], tps_output=new["tps_output"], output2=new["output2"],
+               mask2=new["mask2"].repeat(1, 3, 1, 1))
     to_pillow(out["H_warp"]).save(result_path + "H_warp.jpg")
     to_pillow(out["final_warp"]).save(result_path + "flow_warp.jpg")
     to_pillow(out["output1"]).save(result_path + "warp1.jpg")
-    to_pillow(out["output2"]).save(result_path + "warp2.jpg")
+    to_pillow(out["output2"]).save(result_path + "warp2.jpg")                                             # out.py:265-272
     for key in ("mask1", "mask2"):
         m = (out[key] > 0.5)[0, 0].cpu().to(torch.uint8).numpy() * 255
         Image.fromarray(m).save(result_path + key + ".jpg")
-    to_pillow(out["blend_image"].float()).save(result_path + "ave_fusion.jpg")
+    to_pillow(out["new_blend_image"].float()).save(result_path + "ave_fusion.jpg")
     if composition_model is not None:
         # out.py:277-312: learned seam masks + composed image from the UDIS2 composition network
-        import stitch_amd
         mask1, mask2 = (out["mask1"] > 0.5).float(), (out["mask2"] > 0.5).float()
         comp = stitch_amd.composition.compose(composition_model, out["output1"], out["output2"], mask1, mask2)
         st = ((comp["stitched_image"][0] + 1) * 127.5).cpu().numpy().transpose(1, 2, 0).clip(0, 255).astype(np.uint8)

@@ -12,6 +12,7 @@ from .config import CfgNode, load_inference_config, load_model_config  # noqa: E
 from .flowformer import FlowFormer, build_flowformer  # noqa: E402,F401
 from .homography import UDIS2Network  # noqa: E402,F401
 from . import composition  # noqa: E402,F401
+from . import tps_pipeline  # noqa: E402,F401
 
 
 def build_model(cfg=None):

@@ -1,0 +1,389 @@
+// TPS post-pipeline kernels (reference: core/inference/tps_pipline.py, sample_point_methods.py,
+// utils.py, tps_methods/kornia_tps.py).  gfx950 only.  Compiled with -ffp-contract=off: the reference evaluates these
+// stages as chains of separate torch-CPU ops (one fp32 rounding each) and the kernels keep exactly those roundings,
+// so everything except the TPS solve / kernel sum (an MKL LU and a vectorised reduction in the reference) is bit-exact.
+//
+//   flow_boxavg_kernel     preprocess (tps_pipline.py:213-244): zero-padded k x k mean, negate, * valid
+//   sobel_mag_kernel       |Sobel_x|, |Sobel_y| per channel, channel means, sum (sample_point_methods.py:70-90)
+//   range_argmax_kernel    first arg-max of that magnitude inside each border range window (:93-113)
+//   gather_points_kernel   plane values at integer points (utils.py:61-68 flow lookup, tps_pipline.py:111-128 mask filter)
+//   tps2_solve_kernel      kornia get_tps_transform system [K P; P^T 0] w = [dst; 0], fp64 Gauss-Jordan
+//   tps2_warp_kernel       kornia warp_points_tps on the normalised mesh + grid_sample(bilinear, zeros, align_corners=False)
+//   minmax_filter_kernel   cv2.erode / cv2.dilate with a k x k rectangle (window clipped to the image = OpenCV's default border)
+//   tps_mix_blend_kernel   mask algebra, mix with the flow warp, uint8 blend (tps_pipline.py:139-176)
+#include "common.h"
+#include "../../include/stitch_gfx950.h"
+
+__device__ __forceinline__ float lin_at2(float start, float end, int n, int i) {       // torch.linspace, fp32 (see geom.hip)
+    if (n == 1) return start;
+    const float step = (end - start) / (float)(n - 1);
+    return (i < n / 2) ? __fmaf_rn(step, (float)i, start) : __fmaf_rn(-step, (float)(n - 1 - i), end);
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.pad(zeros) + F.avg_pool2d(k, stride 1) = row-major window sum / k^2 (ATen's CPU kernel order, measured bit for bit);
+// the following F.interpolate to the same size is the identity.  Then optional negation and * valid.
+__global__ __launch_bounds__(256) void flow_boxavg_kernel(const float* __restrict__ in, const float* __restrict__ valid,
+                                                          float* __restrict__ out, int planes, int planes_per_b, int H, int W,
+                                                          int k, int negate) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), p = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const float* im = in + (size_t)p * H * W;
+    const int r = (k - 1) / 2;
+    float s = 0.f;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            s = s + ((yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(size_t)yy * W + xx] : 0.f);
+        }
+    float v = s / (float)(k * k);
+    if (negate) v = -v;
+    if (valid) v = v * valid[(size_t)(p / planes_per_b) * H * W + (size_t)y * W + x];
+    out[(size_t)p * H * W + (size_t)y * W + x] = v;
+}
+
+extern "C" int st_flow_boxavg(const float* flow, const float* valid, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                              int32_t k, int32_t negate, void* stream) {
+    if (!flow || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || k < 1 || !(k & 1)) return ST_EINVAL;
+    dim3 grid((W + 63) / 64, (H + 3) / 4, B * C);
+    hipLaunchKernelGGL(flow_boxavg_kernel, grid, dim3(256), 0, (hipStream_t)stream, flow, valid, out, B * C, C, H, W, k, negate);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// grad = mean_c |conv(x_c, Sx)| + mean_c |conv(x_c, Sy)|, zero padding 1; taps accumulated in row-major order (what
+// torch's depthwise conv2d does on CPU: measured bit for bit), channel mean = ((c0 + c1) + c2 ...) / C.
+__global__ __launch_bounds__(256) void sobel_mag_kernel(const float* __restrict__ img, float* __restrict__ grad, int C, int H, int W) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float kx[9] = {-1.f, 0.f, 1.f, -2.f, 0.f, 2.f, -1.f, 0.f, 1.f};
+    const float ky[9] = {-1.f, -2.f, -1.f, 0.f, 0.f, 0.f, 1.f, 2.f, 1.f};
+    float sx = 0.f, sy = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* im = img + (size_t)c * H * W;
+        float gx = 0.f, gy = 0.f;
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(size_t)yy * W + xx] : 0.f;
+            gx = gx + kx[t] * v;
+            gy = gy + ky[t] * v;
+        }
+        sx = c == 0 ? fabsf(gx) : sx + fabsf(gx);
+        sy = c == 0 ? fabsf(gy) : sy + fabsf(gy);
+    }
+    grad[(size_t)y * W + x] = fabsf(sx / (float)C) + fabsf(sy / (float)C);
+}
+
+extern "C" int st_sobel_magnitude(const float* img, float* grad, int32_t C, int32_t H, int32_t W, void* stream) {
+    if (!img || !grad || C <= 0 || H <= 0 || W <= 0) return ST_EINVAL;
+    hipLaunchKernelGGL(sobel_mag_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, img, grad, C, H, W);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One workgroup per range (x1, y1, x2, y2): arg-max of grad over rows [y1-2, y2+2) x cols [x1-2, x2+2) (clipped to the
+// image like a Python slice; starts must be >= 0, i.e. pad_num >= 2), ties -> the first element in row-major order
+// (torch.argmax).  Everything outside the window is -1 in the reference, so an empty window returns flat index 0.
+__global__ __launch_bounds__(256) void range_argmax_kernel(const float* __restrict__ grad, const int* __restrict__ ranges,
+                                                           int* __restrict__ out, int H, int W) {
+    const int r = blockIdx.x;
+    const int x1 = ranges[4 * r], y1 = ranges[4 * r + 1], x2 = ranges[4 * r + 2], y2 = ranges[4 * r + 3];
+    const int xa = x1 - 2, xb = min(x2 + 2, W), ya = y1 - 2, yb = min(y2 + 2, H);
+    const int ww = xb - xa, hh = yb - ya;
+    float best = -2.f;
+    int bidx = 0x7fffffff;
+    if (ww > 0 && hh > 0)
+        for (int e = threadIdx.x; e < ww * hh; e += 256) {
+            const int yy = ya + e / ww, xx = xa + e % ww;
+            const float v = grad[(size_t)yy * W + xx];
+            const int idx = yy * W + xx;
+            if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+        }
+    __shared__ float sb[256];
+    __shared__ int si[256];
+    sb[threadIdx.x] = best; si[threadIdx.x] = bidx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float ov = sb[threadIdx.x + s];
+            const int oi = si[threadIdx.x + s];
+            if (ov > sb[threadIdx.x] || (ov == sb[threadIdx.x] && oi < si[threadIdx.x])) { sb[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[r] = (si[0] == 0x7fffffff) ? 0 : si[0];
+}
+
+extern "C" int st_range_argmax(const float* grad, const int32_t* ranges, int32_t* out_flat_idx, int32_t n_ranges, int32_t H,
+                               int32_t W, void* stream) {
+    if (!grad || !ranges || !out_flat_idx || n_ranges <= 0 || H <= 0 || W <= 0) return ST_EINVAL;
+    hipLaunchKernelGGL(range_argmax_kernel, dim3(n_ranges), dim3(256), 0, (hipStream_t)stream, grad, ranges, out_flat_idx, H, W);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[i, p] = planes[p, y_i, x_i]  (points are (x, y) int32; callers guarantee they are inside the image)
+__global__ void gather_points_kernel(const float* __restrict__ planes, const int* __restrict__ pts, float* __restrict__ out,
+                                     int n, int P, int H, int W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * P) return;
+    const int pt = i / P, p = i % P;
+    const int x = pts[2 * pt], y = pts[2 * pt + 1];
+    out[i] = (x >= 0 && x < W && y >= 0 && y < H) ? planes[((size_t)p * H + y) * W + x] : 0.f;
+}
+
+extern "C" int st_gather_points(const float* planes, const int32_t* points_xy, float* out, int32_t n, int32_t P, int32_t H,
+                                int32_t W, void* stream) {
+    if (!planes || !points_xy || !out || n <= 0 || P <= 0) return ST_EINVAL;
+    hipLaunchKernelGGL(gather_points_kernel, dim3((n * P + 255) / 256), dim3(256), 0, (hipStream_t)stream, planes, points_xy, out,
+                       n, P, H, W);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kornia TPS.  U(d2) = 0.5 * d2 * log(d2 + 1e-8), d2(a, b) = clamp(-2 a.b + |a|^2 + |b|^2, 0) evaluated in fp32 in that
+// operation order (kornia's _pair_square_euclidean / _kernel_distance).  mode 1 ("pixel"): d2 = |a - b|^2 directly and
+// U = d2 * log(d2 + 1.19e-7) -- the plain r^2 log r^2 spline in pixel units that OpenCV's ThinPlateSplineShapeTransformer
+// fits (same interpolant; the 1/2 is absorbed by the weights).
+__device__ __forceinline__ float tps2_u(float ax, float ay, float bx, float by, int mode) {
+    if (mode == 1) {
+        const float dx = ax - bx, dy = ay - by;
+        const float d2 = dx * dx + dy * dy;
+        return d2 * logf(d2 + 1.1920929e-7f);
+    }
+    const float dot = __fmaf_rn(ay, by, ax * bx);                   // [N,2] @ [2,M]: torch's k = 2 contraction
+    const float a2 = ax * ax + ay * ay, b2 = bx * bx + by * by;
+    float d2 = (-2.0f * dot + a2) + b2;
+    d2 = fmaxf(d2, 0.0f);
+    return 0.5f * d2 * logf(d2 + 1e-8f);
+}
+
+// f(A_i) = rhs_i for f(v) = a0 + [ax ay].v + sum_j w_j U(v, Bp_j): L = [[K, P], [P^T, 0]], K_ij = U(A_i, Bp_j), P = [1, A],
+// right-hand side [rhs; 0].  kornia's get_tps_transform(points_src = A, points_dst = Bp) puts the kernel centres AND the
+// values at Bp (rhs = Bp); the classical spline (OpenCV) has its centres at the sites (Bp = A).  fp64 Gauss-Jordan with partial pivoting on
+// work [n+3, n+5]; weights out: kernel [n,2], affine [3,2] fp32.  (The reference solves in fp32 through MKL's blocked LU,
+// whose operation order is not reproducible; the fp64 solve is the exact solution of the same fp32 system.)
+__global__ __launch_bounds__(256) void tps2_solve_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
+                                                         const float* __restrict__ rhs, double* __restrict__ work,
+                                                         float* __restrict__ kw, float* __restrict__ aw, int n, int mode) {
+    const int n3 = n + 3, ld = n + 5;
+    __shared__ int s_piv;
+    __shared__ double s_best[256];
+    __shared__ int s_idx[256];
+    for (int e = threadIdx.x; e < n3 * ld; e += 256) {
+        const int r = e / ld, c = e % ld;
+        double v = 0.0;
+        if (r < n) {
+            if (c < n) v = tps2_u(A[2 * r], A[2 * r + 1], Bp[2 * c], Bp[2 * c + 1], mode);
+            else if (c == n) v = 1.0;
+            else if (c < n3) v = A[2 * r + (c - n - 1)];
+            else v = rhs[2 * r + (c - n3)];
+        } else if (c < n) {
+            const int k = r - n;
+            v = (k == 0) ? 1.0 : A[2 * c + (k - 1)];
+        }
+        work[e] = v;
+    }
+    __syncthreads();
+    for (int c = 0; c < n3; ++c) {
+        double best = -1.0;
+        int bi = c;
+        for (int r = c + threadIdx.x; r < n3; r += 256) {
+            const double a = fabs(work[(size_t)r * ld + c]);
+            if (a > best) { best = a; bi = r; }
+        }
+        s_best[threadIdx.x] = best; s_idx[threadIdx.x] = bi;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double bb = -1.0;
+            int ii = c;
+            for (int t = 0; t < 256; ++t) if (s_best[t] > bb) { bb = s_best[t]; ii = s_idx[t]; }
+            s_piv = ii;
+        }
+        __syncthreads();
+        const int piv = s_piv;
+        if (piv != c)
+            for (int k = threadIdx.x; k < ld; k += 256) {
+                const double t = work[(size_t)c * ld + k];
+                work[(size_t)c * ld + k] = work[(size_t)piv * ld + k];
+                work[(size_t)piv * ld + k] = t;
+            }
+        __syncthreads();
+        const double inv = 1.0 / work[(size_t)c * ld + c];
+        for (int r = threadIdx.x; r < n3; r += 256) {
+            if (r == c) continue;
+            const double f = work[(size_t)r * ld + c] * inv;
+            if (f != 0.0) for (int k = c + 1; k < ld; ++k) work[(size_t)r * ld + k] -= f * work[(size_t)c * ld + k];
+            work[(size_t)r * ld + c] = 0.0;
+        }
+        __syncthreads();
+    }
+    for (int r = threadIdx.x; r < n3; r += 256) {
+        const double d = work[(size_t)r * ld + r];
+        const float wx = (float)(work[(size_t)r * ld + n3] / d), wy = (float)(work[(size_t)r * ld + n3 + 1] / d);
+        if (r < n) { kw[2 * r] = wx; kw[2 * r + 1] = wy; }
+        else { aw[2 * (r - n)] = wx; aw[2 * (r - n) + 1] = wy; }
+    }
+}
+
+extern "C" int st_tps2_solve(const float* sites, const float* centers, const float* values, void* work_f64, float* kernel_w,
+                             float* affine_w, int32_t n, int32_t mode, void* stream) {
+    if (!sites || !centers || !values || !work_f64 || !kernel_w || !affine_w || n < 3 || n > 4096) return ST_EINVAL;
+    hipLaunchKernelGGL(tps2_solve_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sites, centers, values, (double*)work_f64,
+                       kernel_w, affine_w, n, mode);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// warp_image_tps (kornia_tps.py:114-176): coords = create_meshgrid(h, w) in [-1, 1]; warped = sum_i U(coord, center_i) w_i +
+// coord . A[1:3] + A[0]; grid_sample(bilinear, zeros, align_corners).  mode 1: coords are pixel indices, the result is a
+// source pixel position sampled directly (cv2.remap INTER_LINEAR, constant 0 border).
+__global__ __launch_bounds__(256) void tps2_warp_kernel(const float* __restrict__ img, const float* __restrict__ centers,
+                                                        const float* __restrict__ kw, const float* __restrict__ aw,
+                                                        float* __restrict__ out, int C, int H, int W, int n, float kscale,
+                                                        float ascale, int align_corners, int mode) {
+    extern __shared__ float sh[];                 // centers [n,2], kw [n,2]
+    float* s_c = sh;
+    float* s_w = sh + 2 * n;
+    for (int e = threadIdx.x; e < 2 * n; e += 256) { s_c[e] = centers[e]; s_w[e] = kw[e] * kscale; }
+    __syncthreads();
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    float cx, cy;
+    if (mode == 1) { cx = (float)x; cy = (float)y; }
+    else {
+        cx = (lin_at2(0.f, (float)(W - 1), W, x) / (float)(W - 1) - 0.5f) * 2.0f;
+        cy = (lin_at2(0.f, (float)(H - 1), H, y) / (float)(H - 1) - 0.5f) * 2.0f;
+    }
+    float kx = 0.f, ky = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float u = tps2_u(cx, cy, s_c[2 * i], s_c[2 * i + 1], mode);
+        kx = kx + u * s_w[2 * i];
+        ky = ky + u * s_w[2 * i + 1];
+    }
+    const float a0x = aw[0] * ascale, a0y = aw[1] * ascale, a1x = aw[2] * ascale, a1y = aw[3] * ascale, a2x = aw[4] * ascale,
+                a2y = aw[5] * ascale;
+    const float gx = (kx + (cx * a1x + cy * a2x)) + a0x;
+    const float gy = (ky + (cx * a1y + cy * a2y)) + a0y;
+    float ix, iy;
+    if (mode == 1) { ix = gx; iy = gy; }
+    else if (align_corners) { ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1); iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1); }
+    else { ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f; iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f; }
+    const float x0f = floorf(ix), y0f = floorf(iy), x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    const float nw = (x1f - ix) * (y1f - iy), ne = (ix - x0f) * (y1f - iy), sw = (x1f - ix) * (iy - y0f), se = (ix - x0f) * (iy - y0f);
+    const bool fin = fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+    const int x0 = fin ? (int)x0f : -2, y0 = fin ? (int)y0f : -2, x1 = x0 + 1, y1 = y0 + 1;
+    const bool xin0 = x0 >= 0 && x0 < W, xin1 = x1 >= 0 && x1 < W, yin0 = y0 >= 0 && y0 < H, yin1 = y1 >= 0 && y1 < H;
+    const size_t hw = (size_t)H * W;
+    for (int c = 0; c < C; ++c) {
+        const float* im = img + (size_t)c * hw;
+        float v = (xin0 && yin0 ? im[(size_t)y0 * W + x0] : 0.f) * nw;
+        v = __fmaf_rn(xin1 && yin0 ? im[(size_t)y0 * W + x1] : 0.f, ne, v);
+        v = __fmaf_rn(xin0 && yin1 ? im[(size_t)y1 * W + x0] : 0.f, sw, v);
+        v = __fmaf_rn(xin1 && yin1 ? im[(size_t)y1 * W + x1] : 0.f, se, v);
+        out[(size_t)c * hw + (size_t)y * W + x] = v;
+    }
+}
+
+extern "C" int st_tps2_warp(const float* img, const float* centers, const float* kernel_w, const float* affine_w, float* out,
+                            int32_t C, int32_t H, int32_t W, int32_t n, float kernel_scale, float affine_scale,
+                            int32_t align_corners, int32_t mode, void* stream) {
+    if (!img || !centers || !kernel_w || !affine_w || !out || C <= 0 || H < 2 || W < 2 || n < 1 || n > 3800) return ST_EINVAL;
+    const size_t lds = (size_t)4 * n * sizeof(float);
+    hipLaunchKernelGGL(tps2_warp_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), lds, (hipStream_t)stream, img, centers,
+                       kernel_w, affine_w, out, C, H, W, n, kernel_scale, affine_scale, align_corners, mode);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1-D min / max filter of width k along x (axis 0) or y (axis 1), window clipped to the image: two passes = cv2.erode /
+// cv2.dilate with a k x k rectangle and OpenCV's default (ignored) border.
+__global__ __launch_bounds__(256) void minmax_filter_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                            int k, int is_max, int axis) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), p = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const float* im = in + (size_t)p * H * W;
+    const int r = k / 2;
+    float v = is_max ? -INFINITY : INFINITY;
+    for (int d = -r; d <= r; ++d) {
+        const int xx = axis == 0 ? x + d : x, yy = axis == 0 ? y : y + d;
+        if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+        const float t = im[(size_t)yy * W + xx];
+        v = is_max ? fmaxf(v, t) : fminf(v, t);
+    }
+    out[(size_t)p * H * W + (size_t)y * W + x] = v;
+}
+
+extern "C" int st_minmax_filter(const float* in, float* out, int32_t planes, int32_t H, int32_t W, int32_t k, int32_t is_max,
+                                int32_t axis, void* stream) {
+    if (!in || !out || in == out || planes <= 0 || H <= 0 || W <= 0 || k < 1 || !(k & 1)) return ST_EINVAL;
+    dim3 grid((W + 63) / 64, (H + 3) / 4, planes);
+    hipLaunchKernelGGL(minmax_filter_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, H, W, k, is_max, axis);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 0 (tps_pipline.py:139-141): inv = 1 - (mean_c(warped mask) >= 0.5)                        -> inv [h,w]
+// stage 1 (:150-176) with tmask = 1 - open(inv): tps *= tmask; final-warp / image-1 masks; mix; blend uint8.
+__global__ void tps_mask_inv_kernel(const float* __restrict__ wm, float* __restrict__ inv, int C, size_t hw) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    float s = wm[p];
+    for (int c = 1; c < C; ++c) s = s + wm[(size_t)c * hw + p];
+    const float m = (s / (float)C) >= 0.5f ? 1.0f : 0.0f;
+    inv[p] = 1.0f - m;
+}
+
+__global__ void tps_mix_blend_kernel(float* __restrict__ tps, const float* __restrict__ inv_clean, const float* __restrict__ final_warp,
+                                     const float* __restrict__ output1, const float* __restrict__ mask1, float* __restrict__ tmask_o,
+                                     float* __restrict__ mix_o, float* __restrict__ mixmask_o, unsigned char* __restrict__ blend,
+                                     size_t hw) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const float tmask = 1.0f - inv_clean[p];
+    float fw[3], m1[3], t[3];
+    for (int c = 0; c < 3; ++c) {
+        fw[c] = final_warp[c * hw + p]; m1[c] = mask1[c * hw + p];
+        t[c] = tps[c * hw + p] * tmask;                                                   // :151
+        tps[c * hw + p] = t[c];
+    }
+    const float f3 = ((fw[0] >= 3.0f ? 1.f : 0.f) + (fw[1] >= 3.0f ? 1.f : 0.f)) + (fw[2] >= 3.0f ? 1.f : 0.f);
+    const float fmask = (f3 / 3.0f) >= 0.5f ? 1.0f : 0.0f;                                // :154-155
+    const float i3 = ((1.0f - m1[0]) + (1.0f - m1[1])) + (1.0f - m1[2]);
+    const float inv1 = (i3 / 3.0f) >= 0.5f ? 1.0f : 0.0f;                                 // :157-158
+    const float mixmask = fmask + (1.0f - fmask) * tmask * inv1;                          // :160
+    tmask_o[p] = tmask; mixmask_o[p] = mixmask;
+    for (int c = 0; c < 3; ++c) {
+        const float mix = fw[c] * fmask + t[c] * (1.0f - fmask) * inv1;                   // :159
+        const float o2 = mix * mixmask;                                                   // :165
+        mix_o[c * hw + p] = o2;
+        float bl = (output1[c * hw + p] * m1[c] + o2 * mixmask) / (m1[c] + mixmask);      // :171
+        bl = fminf(fmaxf(bl, 0.0f), 255.0f);
+        blend[c * hw + p] = (bl == bl) ? (unsigned char)bl : (unsigned char)0;            // 0/0 = NaN -> 0 like the CPU cast
+    }
+}
+
+extern "C" int st_tps_mask_inv(const float* warped_mask, float* inv, int32_t C, int32_t h, int32_t w, void* stream) {
+    if (!warped_mask || !inv || C <= 0) return ST_EINVAL;
+    const size_t hw = (size_t)h * w;
+    hipLaunchKernelGGL(tps_mask_inv_kernel, dim3((hw + 255) / 256), dim3(256), 0, (hipStream_t)stream, warped_mask, inv, C, hw);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+extern "C" int st_tps_mix_blend(float* tps3, const float* inv_clean, const float* final_warp3, const float* output1_3,
+                                const float* mask1_3, float* tmask, float* mix3, float* mixmask, uint8_t* blend3, int32_t h,
+                                int32_t w, void* stream) {
+    if (!tps3 || !inv_clean || !final_warp3 || !output1_3 || !mask1_3 || !tmask || !mix3 || !mixmask || !blend3) return ST_EINVAL;
+    const size_t hw = (size_t)h * w;
+    hipLaunchKernelGGL(tps_mix_blend_kernel, dim3((hw + 255) / 256), dim3(256), 0, (hipStream_t)stream, tps3, inv_clean, final_warp3,
+                       output1_3, mask1_3, tmask, mix3, mixmask, blend3, hw);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

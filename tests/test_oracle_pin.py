@@ -214,3 +214,48 @@ def test_composition_oracle_matches_reference_golden():
     assert np.abs(net[0, 0, ::2, ::2].numpy() - g["net_out_sub"]).max() < 1e-6
     assert np.abs(out["stitched_image"][0, :, ::4, ::4].numpy() - g["stitched_sub"]).max() < 1e-6
     assert np.abs(out["learned_mask1"][0, :, ::4, ::4].numpy() - g["lm1_sub"]).max() < 1e-6
+
+
+# ---------------------------------------------------------------- TPS post-pipeline
+def _tps_cfg():
+    from types import SimpleNamespace
+    return SimpleNamespace(grid_h=12, grid_w=12, pad_num=4, residual_flow_use_forward=False, flow_limit=-1, add_corner=False,
+                           get_pt_methods=["advanced_uniform_multi"], affine_scale=1.0, kernel_scale=1.0, use_boundary_limit=False,
+                           output2_is_only_tps=True, do_avg_pooling=True)
+
+
+def test_tps_pipeline_oracle_vs_reference_golden():
+    """oracle/tps_pipeline.py against the outputs of the reference's own core/inference functions
+    (tests/golden/tps_pipeline.npz, written by oracle/ref_harness/make_tps_goldens.py)."""
+    from oracle import tps_pipeline as otp
+    g = np.load(os.path.join(GOLDEN, "tps_pipeline.npz"))
+    ih, iw, wmin, hmin, oh, ow = 200, 264, -21, -13, 236, 300
+    case = otp.synthetic_case(5, ih, iw, wmin, hmin, oh, ow)
+    fl = otp.preprocess(case["residual_flow"].clone(), None, True, False, 12, 12)
+    assert np.array_equal(fl[..., ::3, ::3].numpy(), g["pre_flow_out_sub"])
+    crop = case["H_warp"][:, :, abs(hmin):abs(hmin) + ih, abs(wmin):abs(wmin) + iw]
+    for pad in (4, 22, 44):
+        assert np.array_equal(otp.advanced_uniform_sample_border_points(crop, max(ih, iw) // 12, pad).numpy(), g[f"sample_pts_pad{pad}"]), pad
+    bp = otp.advanced_uniform_sample_border_points(crop, 22, 4)
+    s, t = otp.get_point_pairs(bp, fl, -1)
+    assert np.array_equal(s.numpy(), g["pairs_src"]) and np.array_equal(t.numpy(), g["pairs_tgt"])
+    s2, t2 = otp.get_point_pairs(bp, fl * 8, 20)
+    assert np.array_equal(s2.numpy(), g["pairs_lim_src"]) and np.array_equal(t2.numpy(), g["pairs_lim_tgt"])
+    bs, bd = otp.boundary_src_and_tgt(s.float() * 1.2 - 10, t * 1.2 - 10, oh, ow)
+    assert np.array_equal(bs.numpy(), g["bound_src"]) and np.array_equal(bd.numpy(), g["bound_dst"])
+    img = case["H_warp"][:, :, ::2, ::2].contiguous()
+    ps, pd = T(g["tps_ps"]), T(g["tps_pd"])
+    kw, aw = otp.get_tps_transform(pd, ps)
+    assert np.array_equal(kw.numpy(), g["tps_kw"]) and np.array_equal(aw.numpy(), g["tps_aw"])
+    tw = otp.warp_image_tps(img, ps, kw, aw)
+    assert np.array_equal(tw[..., ::2, ::2].numpy(), g["tps_warp_sub"])
+    for name in ("a", "b"):
+        ih, iw, wmin, hmin, oh, ow, seed = (int(v) for v in g[f"pipe_{name}_dims"])
+        case = otp.synthetic_case(seed, ih, iw, wmin, hmin, oh, ow)
+        res = otp.tps_H_warp(case, dict(width_min=wmin, height_min=hmin, out_height=oh, out_width=ow), _tps_cfg())
+        assert np.array_equal(res["new_blend_image"].numpy(), g[f"pipe_{name}_blend"]), name
+        assert np.array_equal(res["tps_output"][..., ::4, ::4].numpy(), g[f"pipe_{name}_tps_sub"])
+        assert np.array_equal(res["output2"][..., ::4, ::4].numpy(), g[f"pipe_{name}_output2_sub"])
+        assert np.array_equal(np.packbits((res["mask2"].numpy() >= 0.5).astype(np.uint8).reshape(-1)), g[f"pipe_{name}_mask2_bits"])
+        assert np.array_equal(np.packbits((res["mix_tps_flow_warp_mask"].numpy() >= 0.5).astype(np.uint8).reshape(-1)),
+                              g[f"pipe_{name}_mixmask_bits"])

@@ -187,7 +187,7 @@ def test_out_harness_writes_the_reference_file_set(tmp_path, seeded_sd):
     ck = tmp_path / "ckpts" / "seeded" / "final_ckpt"
     ck.parent.mkdir(parents=True)
     torch.save({"module." + k: v for k, v in seeded_sd.items()}, str(ck))
-    save_root = outmod.main(["--data_root_path", str(root) + "/", "--restore_ckpt", str(ck)])
+    save_root = outmod.main(["--data_root_path", str(root) + "/", "--ckpt_path", str(ck)])       # the reference's flag (out.py:18)
     assert "ours__seeded_advanced_uniform_multi_all_img1_with_inpaint_g12" in save_root
     files = sorted(os.listdir(os.path.join(save_root, "demo1")))
     # the 7 warp-stage JPEGs + the 3 files of the composition stage (out.py:303-312; cfg.use_composition is on in this plugin)
