@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=1, help="pairs per forward: 1 = BASELINE configs[1] (default), 8 = configs[2]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL; gloo for CPU rehearsal of the launcher)")
     ap.add_argument("--dry-run", action="store_true", help="launcher/collective plumbing only: no GPU, no model (tests/test_dist_cpu.py)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank computes on cuda:0 (use with --backend gloo; RCCL needs one GPU per rank)")
     return ap.parse_args(argv)
 
 
@@ -62,7 +63,7 @@ def launcher_command(args, port):
     fwd = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
            "--streams", str(args.streams), "--batch", str(args.batch), "--backend", args.backend]
     for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-corr-roofline", args.no_corr_roofline),
-                     ("--eager", args.eager), ("--dry-run", args.dry_run)):
+                     ("--eager", args.eager), ("--dry-run", args.dry_run), ("--share-gpu", args.share_gpu)):
         if on:
             fwd.append(flag)
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -199,6 +200,8 @@ def worker(args):
                               "gathered_ranks": sorted({int(g[0]) for g in gathered})}), flush=True)
         dist.destroy_process_group()
         return
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if "RANK" in os.environ and "MASTER_PORT" in os.environ:      # launched by torch.distributed.run (also with 1 rank)
         import torch.distributed as dist
@@ -222,13 +225,33 @@ def worker(args):
         # configs[3]: 1024x1024 pairs, 4 per GPU, each its own test_out call (batch 1: the canvas is per pair)
         pairs = [tuple(t.cuda() for t in structured_pair(1024, 1024, seed=900 + 8 * rank + i, shift=(11 - 3 * i, 5 * i - 9)))
                  for i in range(4)]
-        nb, nstreams = 1, 1
-        streams = [torch.cuda.current_stream()]
+        nb = 1
+        nstreams = 1 if args.eager else max(1, args.streams)
+        # the network part of test_out (no host sync) replays from a hipGraph; the canvas part stays eager (its shapes depend
+        # on the bounds read back to the host).  One graph + HIP stream per pair in flight.
+        fwds = [(lambda x, y: model(x, y, type="test_out")) if args.eager else model.graphed_test_out() for _ in range(nstreams)]
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
 
-        def step(i=0):
+        pending = []
+
+        def finish_one():
+            g, h, st = pending.pop(0)
+            with torch.cuda.stream(st):
+                o = g.finish(h) if g is not None else h
+                return o["blend_image"].float().mean().double().reshape(1)     # a per-pair scalar for the final gather
+
+        def step(i=0, n_in_flight=None, drain=False):
+            """software pipeline over the pairs in flight: enqueue pair i's network graph, then finish (bounds read-back +
+            canvas kernels) the oldest pair whose graph was enqueued n_in_flight - 1 steps ago"""
+            depth = n_in_flight or nstreams
+            k = i % depth
             a, b = pairs[i % len(pairs)]
-            o = model(a, b, type="test_out")
-            return o["blend_image"].float().mean().double().reshape(1)         # a per-pair scalar for the final gather
+            with torch.cuda.stream(streams[k]):
+                if args.eager:
+                    pending.append((None, model(a, b, type="test_out"), streams[k]))
+                else:
+                    pending.append((fwds[k], fwds[k].launch(a, b), streams[k]))
+            return finish_one() if (len(pending) >= depth or drain) else None
         a, b = pairs[0]
     else:
         ps = [structured_pair(512, 512, seed=7 + rank + 100 * i) for i in range(max(1, args.batch))]
@@ -251,6 +274,10 @@ def worker(args):
             dist.barrier()
         t0 = time.perf_counter()
         vals = [step(i, **kw) for i in range(nsteps)]
+        if big:
+            vals = [v for v in vals if v is not None]
+            while pending:
+                vals.append(finish_one())
         for st in streams[1:]:
             torch.cuda.current_stream().wait_stream(st)
         metric = torch.stack(vals)
@@ -269,10 +296,12 @@ def worker(args):
     log("model built, warming up")
     for i in range(max(args.warmup, nstreams)):
         step(i)
+    while big and pending:
+        finish_one()
     log("timed region")
     dt = timed(args.steps)
     dt1 = None
-    if not big and nstreams > 1:
+    if nstreams > 1:
         dt1 = timed(max(10, args.steps // 2), n_in_flight=1)       # same graphs, one pair in flight (latency-bound figure)
 
     if rank == 0:
@@ -298,8 +327,10 @@ def worker(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "pairs_per_step_per_gpu": nb,
-                       "launch": "eager" if (args.eager or big) else "hipGraph replay", "pairs_in_flight": nstreams * nb,
-                       "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective, one all_gather of per-pair metrics"},
+                       "launch": "eager" if args.eager else ("hipGraph replay of the network part + eager canvas part" if big else "hipGraph replay"),
+                       "pairs_in_flight": nstreams * nb,
+                       "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective, one all_gather of per-pair metrics"
+                                      + (" [REHEARSAL: all ranks share cuda:0]" if args.share_gpu else "")},
             "value_1_in_flight": None if dt1 is None else world * max(10, args.steps // 2) * nb / dt1,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_dma_kernel + conv_gemm_kernel (fp32 MFMA implicit GEMM: all st_conv_gemm launches of one step)",
                          "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,

@@ -146,11 +146,20 @@ class FlowHomoAdpater(nn.Module):
 
     # ------------------------------------------------------------------ stitching @ native size (:197-377)
     def test_out_forward(self, input1_tensor, input2_tensor, pad_mode="constant", preprocess_callback=None):
+        nets = self._test_out_nets(input1_tensor, input2_tensor)
+        return self._test_out_canvas(input1_tensor, input2_tensor, nets)
+
+    def _test_out_nets(self, input1_tensor, input2_tensor):
+        """First part of test_out_forward (:204-266): both networks at 512x512, native-resolution DLT and the mesh bounds.
+        No host synchronisation and a fixed launch sequence for a given input shape, so it can be replayed from a hipGraph
+        (``GraphedTestOut``); everything it returns is a device tensor."""
         if self.use_forward:
             raise NotImplementedError
         if not _flag(self.cfg, "test_not_use_combine_h_flow") or _flag(self.cfg, "use_whole_resolution"):
             raise NotImplementedError("only the shipped branch (test_not_use_combine_h_flow=True, use_whole_resolution=False, "
                                       "flowHomoAdpater.py:303-360) is implemented")
+        if not _flag(self.cfg, "use_fb_consistency_mask"):
+            raise NotImplementedError("shipped inference config sets use_fb_consistency_mask=True (flowHomoAdpater.py:324)")
         dev = input1_tensor.device
         B, _, img_h, img_w = input1_tensor.shape
         if B != 1:
@@ -168,11 +177,20 @@ class FlowHomoAdpater(nn.Module):
         warp_mask_512 = ops.mean_threshold(out_H[:, 3:6].contiguous(), 0.5)                            # :233-234
         flow512, back512 = self.predict_flow_pair(a512, warp2_512)                                     # :236 and :326, one batch
         residual = ops.resize_bilinear(flow512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))  # :241
+        back = ops.resize_bilinear(back512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))
         H = torch.empty((B, 3, 3), device=dev)
         ops.dlt4(self._corners(dev, float(img_w), float(img_h)), motion, H, B, img_w / 512.0, img_h / 512.0, 1.0)  # :244-253
         bounds = torch.empty((4,), device=dev)
         ops.mesh_bounds(H, bounds, img_w, img_h)                                                       # :254-266
-        mnx, mxx, mny, mxy = bounds.tolist()                                                           # the path's host sync (:268,367)
+        return dict(residual=residual, back=back, H=H, bounds=bounds, warp2_512=warp2_512, warp_mask_512=warp_mask_512)
+
+    def _test_out_canvas(self, input1_tensor, input2_tensor, nets):
+        """Second part (:268-377): the canvas size is read back to the host (the path's one sync), then the canvas-sized
+        homography warps, the flow warp, occlusion mask and the blend."""
+        dev = input1_tensor.device
+        B, _, img_h, img_w = input1_tensor.shape
+        residual, back, H = nets["residual"], nets["back"], nets["H"]
+        mnx, mxx, mny, mxy = nets["bounds"].tolist()                                                   # the path's host sync (:268,367)
         width_max, width_min = int(max(float(img_w), mxx)), int(min(0.0, mnx))                         # .int() truncation
         height_max, height_min = int(max(float(img_h), mxy)), int(min(0.0, mny))
         out_width, out_height = width_max - width_min, height_max - height_min                         # :270-271
@@ -191,9 +209,6 @@ class FlowHomoAdpater(nn.Module):
         homo_output2 = ops.homo_warp(input2_tensor, H_mat.view(B, 9), canvas, n_ones=3)                # :310
         rf = ops.homo_warp(residual, I_mat.view(1, 9), canvas, n_ones=1)                               # :313-314
         final = ops.flow_warp(homo_output2, rf[:, 0:2].contiguous(), rf[:, 2:3].contiguous())          # :316-317
-        if not _flag(self.cfg, "use_fb_consistency_mask"):
-            raise NotImplementedError("shipped inference config sets use_fb_consistency_mask=True (flowHomoAdpater.py:324)")
-        back = ops.resize_bilinear(back512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))
         occ = ops.occlusion_from_range(ops.range_map(back), False)                                     # :332
         origin_occ = ops.morph_open(occ, 19)                                                           # :333-334
         occ_c = ops.homo_warp(origin_occ, I_mat.view(1, 9), canvas)                                    # :335
@@ -201,9 +216,61 @@ class FlowHomoAdpater(nn.Module):
         output2, mask1, mask2, blend = ops.blend(homo_output, homo_output2, final, occ_c)              # :339-360
         return dict(H_warp=homo_output2[:, 0:3], final_warp=final[:, 0:3], output1=homo_output[:, 0:3], output2=output2,
                     mask1=mask1, mask2=mask2, blend_image=blend, residual_flow=residual, width_min=width_min,
-                    height_min=height_min, out_height=out_height, out_width=out_width, H=Hc, warp_input2_mask=warp_mask_512,
-                    warp_input2_tensor_512=warp2_512, I_mat=I_mat, H_warp_mask=homo_output2[:, 3:6], occlusion_mask=occ_c,
-                    origin_occlusion_mask=origin_occ)
+                    height_min=height_min, out_height=out_height, out_width=out_width, H=Hc,
+                    warp_input2_mask=nets["warp_mask_512"], warp_input2_tensor_512=nets["warp2_512"], I_mat=I_mat,
+                    H_warp_mask=homo_output2[:, 3:6], occlusion_mask=occ_c, origin_occlusion_mask=origin_occ)
+
+    def graphed_test_out(self):
+        """hipGraph replay of the network part of ``forward(type="test_out")`` (see ``GraphedTestOut``)."""
+        return GraphedTestOut(self)
+
+
+class GraphedTestOut:
+    """``forward(type="test_out")`` with its network part (both nets at 512x512, DLT, mesh bounds: ~1 000 launches, no host
+    sync) replayed from a hipGraph per input shape; the canvas part, whose shapes depend on the read-back bounds, stays
+    eager.  ``residual_flow`` / ``warp_input2_*`` live in the graph's static buffers: consume them before the next call."""
+
+    def __init__(self, model):
+        self.model = model
+        self._graphs = {}
+
+    def __call__(self, input1_tensor, input2_tensor):
+        return self.finish(self.launch(input1_tensor, input2_tensor))
+
+    def launch(self, input1_tensor, input2_tensor):
+        """Enqueue the network part on the current stream (asynchronous) and return a handle for ``finish``.  Several
+        GraphedTestOut objects on several streams can be launched before any of them is finished, so that the host-side
+        wait of one pair (the canvas bounds) overlaps with the other pairs' kernels."""
+        m = self.model
+        if m.training:
+            raise NotImplementedError("inference-only drop-in: call .eval() first")
+        key = (tuple(input1_tensor.shape), input1_tensor.device.index)
+        ent = self._graphs.get(key)
+        with torch.no_grad():
+            if ent is None:
+                a, b = input1_tensor.float().contiguous().clone(), input2_tensor.float().contiguous().clone()
+                ws = ops.new_workspace(a.device)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side), ops.workspace_scope(ws):
+                    for _ in range(2):
+                        m._test_out_nets(a, b)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph), ops.workspace_scope(ws):
+                    nets = m._test_out_nets(a, b)
+                ent = self._graphs[key] = (graph, a, b, nets, ws)
+            graph, a, b, nets = ent[:4]
+            a.copy_(input1_tensor)
+            b.copy_(input2_tensor)
+            graph.replay()
+        return (a, b, nets, torch.cuda.current_stream())
+
+    def finish(self, handle):
+        a, b, nets, stream = handle
+        with torch.no_grad(), torch.cuda.stream(stream):
+            return self.model._test_out_canvas(a, b, nets)
 
 
 class GraphedForward:

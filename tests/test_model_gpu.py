@@ -297,3 +297,24 @@ def test_graph_replay_and_concurrent_streams_match_eager(model):
         torch.cuda.synchronize()
         for e, o in zip(eager, outs):
             assert torch.equal(e, o)
+
+
+def test_graphed_test_out_matches_eager(model):
+    """network part of `test_out` replayed from a hipGraph + eager canvas part == the eager forward, bit for bit, also when
+    two pairs are launched before either is finished (the bench's software pipeline)."""
+    pairs = [inputs.structured_pair(320, 416, seed=70 + i, shift=(4 - 3 * i, 2 * i - 5)) for i in range(2)]
+    eager = [model(a.cuda(), b.cuda(), type="test_out") for a, b in pairs]
+    gs = [model.graphed_test_out() for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    for rep in range(2):
+        handles = []
+        for i, (a, b) in enumerate(pairs):
+            streams[i].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[i]):
+                handles.append(gs[i].launch(a.cuda(), b.cuda()))
+        outs = [gs[i].finish(h) for i, h in enumerate(handles)]
+        torch.cuda.synchronize()
+        for e, o in zip(eager, outs):
+            assert [o[k] for k in ("width_min", "height_min", "out_height", "out_width")] == [e[k] for k in ("width_min", "height_min", "out_height", "out_width")]
+            for k in ("blend_image", "output2", "mask2", "residual_flow", "occlusion_mask", "H"):
+                assert torch.equal(e[k], o[k]), k
