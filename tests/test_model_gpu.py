@@ -230,13 +230,19 @@ def test_end_to_end_test_eval_512_vs_reference_golden(model):
                       "origin_occlusion_mask"}
     assert o["output_H"].shape == (1, 6, 512, 512) and o["overlap"].shape == (1, 512, 512)
     assert o["origin_occlusion_mask"].shape == (1, 512, 512) and o["H"].shape == (1, 3, 3)
+    # End-to-end bounds.  Stage by stage with the oracle's intermediates held fixed the path is bit-exact (homography stage,
+    # flow warp, occlusion) or as close to the fp64 answer as the reference's own fp32 evaluation (flow network):
+    # tests/test_parity_gpu.py.  End to end the two paths start from corner offsets that differ by ~1e-5 px (H by ~1.5e-6),
+    # and the seeded random-weight flow network amplifies that: the CPU oracle itself moves by flow max 0.06 / p99 0.017 px
+    # and ~800 occlusion pixels when fed the HIP offsets (profiles/r2_parity.json, oracle_sensitivity), and the HIP path
+    # against ITSELF at batch 8 vs batch 1 (another summation order) by 0.12 px / 950 pixels (test_forward_batch8 below).
     H = o["H"].cpu().numpy()
-    assert np.abs(H - g["H"]).max() < 5e-3 * max(1.0, np.abs(g["H"]).max())
+    assert np.abs(H - g["H"]).max() < 6e-6 * max(1.0, np.abs(g["H"]).max())            # measured 1.6e-6
     flow = o["flow_predictions"][0].cpu()
     dflow = np.abs(flow[..., ::8, ::8].numpy() - g["flow_sub"])
-    assert dflow.max() < 0.5 and np.percentile(dflow, 99) < 5e-2, (dflow.max(), np.percentile(dflow, 99))
+    assert dflow.max() < 0.3 and np.percentile(dflow, 99) < 5e-2, (dflow.max(), np.percentile(dflow, 99))   # measured 0.085 / 0.026
     dH = np.abs(o["output_H"][..., ::8, ::8].cpu().numpy() - g["output_H_sub"])
-    assert np.percentile(dH, 99) < 0.5, np.percentile(dH, 99)
+    assert np.percentile(dH, 99) < 1e-2, np.percentile(dH, 99)                          # measured 1.7e-3
     occ_flip = np.unpackbits(_bits(o["origin_occlusion_mask"]) ^ g["occ_bits"]).sum()
     ov_flip = np.unpackbits(_bits(o["overlap"]) ^ g["overlap_bits"]).sum()
     assert occ_flip < 0.01 * 512 * 512 and ov_flip < 0.01 * 512 * 512, (occ_flip, ov_flip)
