@@ -105,17 +105,20 @@ class FlowFormer(ParamTree):
         # Fold them through the key projection (scores against un-projected tokens; the key bias cancels in the softmax)
         # and fold the value bias through the output projection (softmax weights sum to one).
         with torch.no_grad():
+            # weight-only constant folding at load time, in fp64 on the HOST (a few 8x128 / 128x128 products: no GPU library call)
             L = pk["xin"]
-            lat = p[c + "latent_tokens"][0].double()
-            qn = torch.nn.functional.layer_norm(lat, (lat.shape[1],), L["n1"][0].double(), L["n1"][1].double(), 1e-5)
-            qv = qn @ L["q"][0].double().t() + L["q"][1].double()                        # [nl, 128]
-            Wk, Wv = L["kv"][0][:128].double(), L["kv"][0][128:].double()
-            bv = L["kv"][1][128:].double()
+            dev = L["proj"][0].device
+            c64 = lambda t: t.detach().double().cpu()                                      # noqa: E731
+            lat = c64(p[c + "latent_tokens"][0])
+            qn = torch.nn.functional.layer_norm(lat, (lat.shape[1],), c64(L["n1"][0]), c64(L["n1"][1]), 1e-5)
+            qv = qn @ c64(L["q"][0]).t() + c64(L["q"][1])                                  # [nl, 128]
+            Wk, Wv = c64(L["kv"][0][:128]), c64(L["kv"][0][128:])
+            bv = c64(L["kv"][1][128:])
             nl_, hd = qv.shape[0], 16
             qp = torch.einsum("lhe,hec->lhc", qv.view(nl_, 8, hd), Wk.view(8, hd, 128)) * hd ** -0.5
-            L["qfold"] = qp.reshape(nl_ * 8, 128).float().contiguous()                   # row = latent*8 + head
-            L["wv_heads"] = Wv.float().contiguous()                                      # [8 heads x 16, 128]
-            L["proj_b_fold"] = (L["proj"][1].double() + L["proj"][0].double() @ bv).float().contiguous()
+            L["qfold"] = qp.reshape(nl_ * 8, 128).float().contiguous().to(dev)             # row = latent*8 + head
+            L["wv_heads"] = Wv.float().contiguous().to(dev)                                # [8 heads x 16, 128]
+            L["proj_b_fold"] = (c64(L["proj"][1]) + c64(L["proj"][0]) @ bv).float().contiguous().to(dev)
         pk["self"] = [attn_layer(c + f"encoder_layers.{i}", True) for i in range(HP["encoder_depth"])]
         vert = []
         for i in range(HP["encoder_depth"]):
