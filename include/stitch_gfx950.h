@@ -252,7 +252,7 @@ int st_compose_blend(const float* warp1, const float* warp2, const float* mask1,
 /* out.py:284 normalize_fn: clip(0,255)/127.5 - 1.                                                          */
 int st_compose_normalize(const float* x, float* out, int64_t n, void* stream);
 
-/* ---- TPS post-pipeline (core/inference/*, in-tree "kornia" back-end, no inpainter) ---------------- */
+/* ---- TPS post-pipeline (the core/inference package, in-tree "kornia" back-end, no inpainter) ---------------- */
 /* preprocess (tps_pipline.py:213-244): zero-padded k x k mean of flow [B,C,H,W] (row-major window sum / k^2), optional
  * negation (residual_flow_use_forward = False), optional * valid [B,1,H,W].                                             */
 int st_flow_boxavg(const float* flow, const float* valid, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
