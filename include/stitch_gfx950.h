@@ -291,6 +291,30 @@ int st_tps_mix_blend(float* tps3, const float* inv_clean, const float* final_war
                      const float* mask1_3, float* tmask, float* mix3, float* mixmask, uint8_t* blend3, int32_t h,
                      int32_t w, void* stream);
 
+/* ---- mix_fn plug-ins of the post-pipeline (core/inference/mix_methods/all_img1_with_inpaint.py:8-113,
+ *      inpaint_all_area.py:8-73; helpers core/inference/utils.py:125-170): everything but the neural inpainter ----------- */
+/* F.conv2d(plane, ones(k,k), padding=pad) on the output domain Ho x Wo (even kernels: the reference crops to [:H,:W]),
+ * cmp 0: sum, 1: sum == k*k (erosion of dilate_thin_area), 2: sum >= 1 (its dilations).                                    */
+int st_box_sum_cmp(const float* in, int32_t H, int32_t W, float* out, int32_t Ho, int32_t Wo, int32_t k, int32_t pad,
+                   int32_t cmp, void* stream);
+/* plane ops of dilate_thin_area / thresholds: op 0: o0 = clamp(a*b,0,1), o1 = a*(1-o0); 1: o0 = clamp(a+b,0,1), o1 = (o0>=1);
+ * 2: o0 = a > thr.                                                                                                         */
+int st_mix_plane_op(const float* a, const float* b, float* o0, float* o1, int64_t n, int32_t op, float thr, void* stream);
+/* first lines of mix_fn (method 0: all_img1_with_inpaint.py:44-53, 1: inpaint_all_area.py:43-51): tps_final_warp,
+ * tps_final_warp_mask (3 planes each) and channel 0 of the inpaint-area mask before dilate_thin_area.                       */
+int st_mix_stage_a(const float* final_warp3, const float* occ, const float* mask1_3, const float* tps3, const float* tmask,
+                   float* tfw3, float* tfwm3, float* iam0, int32_t h, int32_t w, int32_t method, void* stream);
+/* all_img1_with_inpaint.py:58-77: border / image-1 fill -> inpaint_img_by_only_img1 (3 planes), channel 0 of the
+ * "inpaint by other" mask before dilate_thin_area.                                                                          */
+int st_mix_stage_b(const float* iam, const float* dil, const float* mask1_3, const float* tfw3, const float* output1_3,
+                   float* only_img1_3, float* other0, int32_t h, int32_t w, void* stream);
+/* out3 = [clip 0..255](img3) * (invert ? 1 - mask : mask); mask NULL = no mask (all_img1_with_inpaint.py:82,85,101).       */
+int st_mix_mul_mask(const float* img3, const float* mask, float* out3, int32_t h, int32_t w, int32_t invert, int32_t clip,
+                    void* stream);
+/* new_blend_image (tps_pipline.py:186-187): clip((output1*mask1 + output2*mask2)/(mask1+mask2), 0, 255) -> uint8.            */
+int st_blend_pair(const float* output1_3, const float* mask1_3, const float* output2_3, const float* mask2, int32_t mask2_planes,
+                  uint8_t* blend3, int32_t h, int32_t w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

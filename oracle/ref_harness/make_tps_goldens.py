@@ -33,7 +33,13 @@ def install_inference_stubs():
     cv2.MORPH_RECT = 0
     cv2.getStructuringElement = lambda shape, ksize: np.ones((ksize[1], ksize[0]), np.uint8)
     cv2.erode = lambda img, k: ndi.minimum_filter(img, footprint=k.astype(bool), mode="constant", cval=np.inf)
-    cv2.dilate = lambda img, k: ndi.maximum_filter(img, footprint=k.astype(bool), mode="constant", cval=-np.inf)
+    def _dilate(img, k, iterations=1):
+        if img.ndim == 3:
+            return np.stack([_dilate(img[..., c], k, iterations) for c in range(img.shape[2])], -1)
+        for _ in range(iterations):
+            img = ndi.maximum_filter(img, footprint=k.astype(bool), mode="constant", cval=0 if img.dtype == np.uint8 else -np.inf)
+        return img
+    cv2.dilate = _dilate
     tv = sys.modules["torchvision"]
     tvf = stubs._mod("torchvision.transforms.functional",
                      crop=lambda img, top, left, height, width: img[..., top:top + height, left:left + width])
@@ -102,6 +108,22 @@ def main():
             out[f"pipe_{name}_mask2_bits"] = np.packbits((res["mask2"].numpy() >= 0.5).astype(np.uint8).reshape(-1))
             out[f"pipe_{name}_mixmask_bits"] = np.packbits((res["mix_tps_flow_warp_mask"].numpy() >= 0.5).astype(np.uint8).reshape(-1))
             out[f"pipe_{name}_output2_sub"] = res["output2"][..., ::4, ::4].contiguous().numpy()
+        # --- the mix_fn plug-ins (inpaint_fn of tps_H_warp) with a pass-through inpainter in place of the neural ones
+        import importlib
+        for mname, ofn in (("all_img1_with_inpaint", otp.mix_all_img1_with_inpaint), ("inpaint_all_area", otp.mix_inpaint_all_area)):
+            ref_mix = importlib.import_module(f"core.inference.mix_methods.{mname}").mix_fn
+            ih, iw, wmin, hmin, oh, ow = 200, 264, -21, -13, 236, 300
+            case = otp.synthetic_case(5, ih, iw, wmin, hmin, oh, ow)
+            inputs = types.SimpleNamespace(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in case.items()})
+            limit = types.SimpleNamespace(width_min=wmin, height_min=hmin, out_height=oh, out_width=ow)
+            inp = otp.PassthroughInpainter()
+            fn = lambda **kw: ref_mix(**kw, inpainter=inp, use_composition=False, is_plot=False, resize_to_area_limit_before_inpaint=750 * 750)  # noqa: E731
+            res = ref_tp.tps_H_warp(inputs, limit, cfg, inpaint_fn=fn, is_plot=False)
+            out[f"mix_{mname}_blend"] = res["new_blend_image"].numpy()
+            out[f"mix_{mname}_output2_sub"] = res["output2"][..., ::4, ::4].contiguous().numpy()
+            out[f"mix_{mname}_output2_cs"] = cs(res["output2"])
+            out[f"mix_{mname}_mask2_bits"] = np.packbits((res["mask2"].numpy() >= 0.5).astype(np.uint8).reshape(-1))
+            out[f"mix_{mname}_area_cs"] = cs(res["inpaint_area_mask"])
     np.savez_compressed(os.path.join(OUT, "tps_pipeline.npz"), **out)
     print({k: v.shape for k, v in out.items()})
     print(os.path.getsize(os.path.join(OUT, "tps_pipeline.npz")), "bytes")

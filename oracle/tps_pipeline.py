@@ -275,3 +275,102 @@ def tps_H_warp(inputs, image_limit, cfg):
         output2, mask2 = tps * tmask, tmask
     res.update(output2=output2, mask2=mask2)
     return res
+
+
+# ================================================================== mix methods (core/inference/mix_methods/*.py)
+# The `mix_fn` plug-ins that `tps_H_warp` calls as `inpaint_fn` (out.py:235-236): everything except the neural inpainter
+# itself is restated here; `inpainter` is any object with `.name` and `.inpaint(img, mask, control_image_tensor=None,
+# prompt="", resize_to_area_limit_before_inpaint=False)` (transref_inpainter.py:16,37).
+class PassthroughInpainter:
+    """Stand-in for the out-of-scope neural inpainters: returns the control image (or the input) unchanged."""
+    name = "passthrough_inpainter"
+
+    def inpaint(self, init_image_tensor, mask_image_tensor, control_image_tensor=None, prompt="", resize_to_area_limit_before_inpaint=False):
+        return (control_image_tensor if control_image_tensor is not None else init_image_tensor).clone()
+
+
+def dilate_thin_area(mask, dilation_kernel_size=8, thickening_kernel_size=8):
+    """core/inference/utils.py:125-160 (channel 0 only; even kernels with padding k//2, results cropped to H x W)."""
+    _, origin_channel, H, W = mask.shape
+    mask = mask[:, 0:1]
+    k = torch.ones((1, 1, dilation_kernel_size, dilation_kernel_size), dtype=mask.dtype)
+    p = dilation_kernel_size // 2
+    erosion = (F.conv2d(mask, k, padding=(p, p)) == k.numel()).float()
+    dilation = (F.conv2d(erosion, k, padding=(p, p)) >= 1).float()[:, :, :H, :W]
+    thick = (mask * dilation).clamp(0, 1)
+    thin = mask * (1 - thick)
+    k2 = torch.ones((1, 1, thickening_kernel_size, thickening_kernel_size), dtype=mask.dtype)
+    p2 = thickening_kernel_size // 2
+    dthin = (F.conv2d(thin, k2, padding=(p2, p2)) >= 1).float()[:, :, :H, :W]
+    return (thick + dthin).clamp(0, 1).repeat(1, origin_channel, 1, 1)
+
+
+def dilate_mask(mask, kernel_size=3):
+    """core/inference/utils.py:163-170: uint8 truncation of the mask (to_pillow_fn), cv2.dilate, channel 0 / 255."""
+    u8 = mask[0].permute(1, 2, 0).to(torch.uint8).float()[None].permute(0, 3, 1, 2)             # values 0 / 1 for masks in [0, 1]
+    d = _rect_filter(u8, kernel_size, True)[:, 0:1] / 255.0
+    return d.repeat(1, 3, 1, 1).to(mask.dtype)
+
+
+def mix_all_img1_with_inpaint(tps_H_warp, tps_H_warp_mask, output1, mask1, final_warp, occlusion_mask, padding=None, residual_flow=None,
+                              inpainter=None, resize_to_area_limit_before_inpaint=950 * 950):
+    """core/inference/mix_methods/all_img1_with_inpaint.py:8-113."""
+    inpainter = inpainter or PassthroughInpainter()
+    inv_mask1 = 1. - torch.where(mask1 > 0.5, torch.ones_like(mask1), torch.zeros_like(mask1))
+    tfw = final_warp * occlusion_mask * mask1 + tps_H_warp * inv_mask1
+    tfwm = occlusion_mask * mask1 + tps_H_warp_mask * inv_mask1
+    iam = dilate_thin_area((1. - tfwm) * mask1)
+    dil = dilate_mask(iam, kernel_size=7)
+    dil = torch.where(dil > 0, torch.ones_like(dil), torch.zeros_like(dil))
+    border = torch.abs(iam - dil)
+    iam = dil
+    by1 = (1 - border) * iam * mask1
+    inpaint_img = tfw * (1 - by1) + (output1 * by1) * by1
+    only_img1 = inpaint_img.clone()
+    other = dilate_thin_area((1. - by1) * border, thickening_kernel_size=8)
+    other = torch.where(other > 0.05, torch.ones_like(other), torch.zeros_like(other))
+    inpaint_img = inpaint_img * (1 - other)
+    if inpainter.name == "transref_inpainter":
+        control = only_img1.clip(0, 255)
+        inpaint_img = inpainter.inpaint(control, other, control_image_tensor=control, resize_to_area_limit_before_inpaint=False)
+    else:
+        big = other.shape[2] * other.shape[3] > resize_to_area_limit_before_inpaint or inpainter.name == "gan_inpainter"
+        inpaint_img = inpainter.inpaint(inpaint_img, other, resize_to_area_limit_before_inpaint=resize_to_area_limit_before_inpaint if big else False)
+    inpaint_img = inpaint_img.float() * tps_H_warp_mask
+    inpaint_img_mask = tps_H_warp_mask
+    if torch.count_nonzero(inpaint_img) != 0:
+        tfw, tfwm = inpaint_img.clone(), inpaint_img_mask.clone()
+    return tfw, tfwm, inpaint_img, inpaint_img_mask, torch.cat((only_img1, other[:, 0:1]), dim=1)
+
+
+def mix_inpaint_all_area(tps_H_warp, tps_H_warp_mask, output1, mask1, final_warp, occlusion_mask, padding=None, residual_flow=None,
+                         inpainter=None, resize_to_area_limit_before_inpaint=950 * 950):
+    """core/inference/mix_methods/inpaint_all_area.py:8-73."""
+    inpainter = inpainter or PassthroughInpainter()
+    inv_mask1 = 1. - mask1
+    tfw = final_warp * occlusion_mask + tps_H_warp * inv_mask1
+    tfwm = occlusion_mask + tps_H_warp_mask * inv_mask1
+    iam = dilate_thin_area((1. - tfwm) * mask1 * tps_H_warp_mask, thickening_kernel_size=16)
+    if inpainter.name == "transref_inpainter":
+        inpaint_img = inpainter.inpaint(tfw, iam, control_image_tensor=output1.clip(0, 255), resize_to_area_limit_before_inpaint=False)
+    else:
+        big = iam.shape[2] * iam.shape[3] > resize_to_area_limit_before_inpaint or inpainter.name == "gan_inpainter"
+        inpaint_img = inpainter.inpaint(tfw, iam, resize_to_area_limit_before_inpaint=resize_to_area_limit_before_inpaint if big else False)
+    inpaint_img_mask = tps_H_warp_mask.clone()
+    if torch.count_nonzero(inpaint_img) != 0:
+        tfw, tfwm = inpaint_img.clone(), inpaint_img_mask.clone()
+    return tfw, tfwm, inpaint_img, inpaint_img_mask, iam
+
+
+def tps_H_warp_with_inpaint(inputs, image_limit, cfg, mix_fn, inpainter=None):
+    """tps_pipline.py:20-205 with inpaint_fn = mix_fn(..., inpainter=...) (out.py:235-236): :178-188."""
+    res = tps_H_warp(inputs, image_limit, cfg)
+    assert cfg.output2_is_only_tps
+    output1, mask1 = inputs["output1"], inputs["mask1"]
+    tfw, tfwm, inpaint_img, inpaint_img_mask, inpaint_area_mask = mix_fn(
+        tps_H_warp=res["output2"].clone(), tps_H_warp_mask=res["mask2"].clone(), output1=output1, mask1=mask1,
+        final_warp=inputs["final_warp"], occlusion_mask=inputs["occlusion_mask"], inpainter=inpainter)
+    blend = ((output1 * mask1 + tfw * tfwm) / (mask1 + tfwm)).clip(0, 255)
+    res.update(output2=tfw, mask2=tfwm, new_blend_image=torch.nan_to_num(blend, nan=0.0).to(torch.uint8),
+               inpaint_img=inpaint_img, inpaint_area_mask=inpaint_area_mask)
+    return res

@@ -6,10 +6,12 @@ SURVEY.md section 8 f-1 / f-3) on the MI355X package.
 Same flags, `demo.txt` pair list (one directory per line holding input1.jpg / input2.jpg), RGB-float loading and
 result-directory naming as the reference.  The forward (`type="test_out"`) and the TPS post-pipeline
 (core/inference/tps_pipline.py, `stitch_amd.tps_pipeline`) run on the HIP kernels; the composition stage (out.py:277-312,
-`cfg.use_composition`) runs on the post-TPS canvases.  Differences from the reference's files, all because the inpainters
-(TransRef / diffusion, fetched weights + third-party CUDA ops) are out of scope: `warp2.jpg`, `mask2.jpg`, `ave_fusion.jpg`,
-`composition.jpg`, `learned_mask*.jpg` hold the post-TPS result BEFORE inpainting; with the shipped `tps_method="opencv"` the
-spline is this package's own pixel-unit TPS (OpenCV is not installable here: unpinned against OpenCV)."""
+`cfg.use_composition`) runs on the post-TPS canvases.  The `mix_fn` plug-in named by `TPS_PIPELINE_CONFIG.mix_method` runs too
+(`stitch_amd.mix_methods`).  Differences from the reference's files: the neural inpainter inside `mix_fn` (TransRef /
+diffusion: fetched weights + third-party CUDA ops) is out of scope and replaced by a pass-through, so in `warp2.jpg`,
+`mask2.jpg`, `ave_fusion.jpg`, `composition.jpg`, `learned_mask*.jpg` the thin border `mix_fn` leaves to the inpainter is not
+synthesised; with the shipped `tps_method="opencv"` the spline is this package's own pixel-unit TPS (OpenCV is not
+installable here: unpinned against OpenCV)."""
 from __future__ import annotations
 
 import argparse
@@ -74,10 +76,24 @@ def to_pillow(t):
 
 
 @torch.no_grad()
-def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_model=None):
-    """out.py:158-312: forward (`test_out`), TPS post-pipeline, saves, composition.  The inpainting step of the reference
-    (mix_fn / inpainter, out.py:235-236) is out of scope: `warp2.jpg`, `mask2.jpg`, `ave_fusion.jpg` and the composition
-    inputs are the post-TPS images BEFORE inpainting (the reference writes the inpainted ones)."""
+def load_inpainter(name):
+    """out.py:341-346: `core.inference.mix_methods.utils.<name>.inpainter`.  The reference's inpainters (TransRef, diffusion)
+    need fetched weights and third-party CUDA ops and are out of scope; a module of that name dropped into
+    `stitch_amd/mix_methods/utils/` is picked up, otherwise the pass-through stand-in is used."""
+    import importlib
+    try:
+        return importlib.import_module(f"stitch_amd.mix_methods.utils.{name}").inpainter
+    except ImportError:
+        print(f"[out.py] inpainter {name!r} is not available here (out of scope): using the pass-through stand-in -- holes keep "
+              f"what mix_fn fills from image 1, the thin border it leaves to the inpainter stays as is")
+        return importlib.import_module("stitch_amd.mix_methods.utils.passthrough_inpainter").inpainter
+
+
+def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_model=None, inpainter=None):
+    """out.py:158-312: forward (`test_out`), TPS post-pipeline with the configured `mix_fn`, saves, composition.  The neural
+    inpainter the reference calls inside `mix_fn` is out of scope (pass-through stand-in unless the caller supplies one): in
+    `warp2.jpg`, `mask2.jpg`, `ave_fusion.jpg` and the composition inputs the holes hold what `mix_fn` fills from image 1, the
+    thin border region it hands to the inpainter is not synthesised."""
     from PIL import Image
     path = data_dict["DATA_PATH"]
     name = os.path.basename(os.path.normpath(path))
@@ -88,7 +104,9 @@ def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_m
     if getattr(cfg, "swap_image", False):
         image1, image2 = image2, image1
     out = warp_model(image1.cuda(), image2.cuda(), type="test_out", pad_mode=cfg.pad_mode)
-    # ---- TPS post-pipeline (out.py:218-258, core/inference/tps_pipline.py:20-205) on the GPU, inpainting excluded
+    if inpainter is None:
+        inpainter = load_inpainter(getattr(cfg.TPS_PIPELINE_CONFIG, "inpainter", "") or "passthrough_inpainter")
+    # ---- TPS post-pipeline incl. the mix_fn plug-in (out.py:218-258, core/inference/tps_pipline.py:20-205) on the GPU
     import stitch_amd
     tpc = cfg.TPS_PIPELINE_CONFIG
     fb = getattr(cfg, "use_fb_consistency_mask", False)
@@ -100,7 +118,11 @@ def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_m
                   final_warp=out["final_warp"], mask2=out["mask2"], residual_flow=out["residual_flow"], valid=valid,
                   occlusion_mask=out["occlusion_mask"], border_points_mask=border_points_mask)
     limit = dict(width_min=out["width_min"], height_min=out["height_min"], out_height=out["out_height"], out_width=out["out_width"])
-    new = stitch_amd.tps_pipeline.tps_H_warp(inputs, limit, tpc, inpaint_fn=None)
+    import importlib
+    mix_fn = importlib.import_module(f"stitch_amd.mix_methods.{tpc.mix_method}").mix_fn                     # out.py:235
+    inpaint_fn = lambda **kw: mix_fn(**kw, inpainter=inpainter, use_composition=tpc.use_composition_when_inpaint,   # noqa: E731
+                                     is_plot=tpc.is_plot, resize_to_area_limit_before_inpaint=tpc.resize_to_area_limit_before_inpaint)
+    new = stitch_amd.tps_pipeline.tps_H_warp(inputs, limit, tpc, inpaint_fn=inpaint_fn)
     out = dict(out, forward_output2=out["output2"], forward_mask2=out["mask2"], forward_blend_image=out["blend_image"],
                new_blend_image=new["new_blend_image"], tps_output=new["tps_output"], output2=new["output2"],
                mask2=new["mask2"].repeat(1, 3, 1, 1))
@@ -144,6 +166,7 @@ def main(argv=None):
         else:
             print(f"[out.py] composition checkpoint {path!r} not found: random-init composition network (plumbing only)")
             composition_model = stitch_amd.composition.Network().cuda().eval()
+    inpainter = load_inpainter(getattr(cfg.TPS_PIPELINE_CONFIG, "inpainter", "") or "passthrough_inpainter")   # out.py:339-346
     model_name = cfg.restore_ckpt.split("/")[-2] if cfg.restore_ckpt.count("/") >= 1 else "random"
     tag = "512" if cfg.resize_to_512 else ""
     tps = cfg.TPS_PIPELINE_CONFIG
@@ -156,7 +179,7 @@ def main(argv=None):
         if cfg.skip_if_avg_fusion_exists and os.path.exists(os.path.join(save_root, os.path.basename(os.path.normpath(dd["DATA_PATH"])), "ave_fusion.jpg")):
             print("[WARNING] Skip, Due to exist", dd["DATA_PATH"])
             continue
-        _, rp = inference_one_data(cfg, dd, save_root, model, composition_model)
+        _, rp = inference_one_data(cfg, dd, save_root, model, composition_model, inpainter)
         print("saved", rp)
     return save_root
 

@@ -13,6 +13,7 @@ from .flowformer import FlowFormer, build_flowformer  # noqa: E402,F401
 from .homography import UDIS2Network  # noqa: E402,F401
 from . import composition  # noqa: E402,F401
 from . import tps_pipeline  # noqa: E402,F401
+from . import mix_methods  # noqa: E402,F401
 
 
 def build_model(cfg=None):

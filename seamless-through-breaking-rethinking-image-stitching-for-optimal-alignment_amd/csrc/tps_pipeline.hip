@@ -387,3 +387,171 @@ extern "C" int st_tps_mix_blend(float* tps3, const float* inv_clean, const float
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
+
+// =============================================================================================
+// mix_fn plug-ins (core/inference/mix_methods/all_img1_with_inpaint.py, inpaint_all_area.py; helpers
+// core/inference/utils.py:125-170).  Everything but the neural inpainter: elementwise mask algebra (one fp32 rounding per
+// torch op, kept) and box sums with the reference's even-kernel geometry.
+
+// F.conv2d(x, ones(k, k), padding=pad) on one plane, output domain Ho x Wo (the reference crops the H+1 / H+2 rows an even
+// kernel produces to [:H, :W]); taps accumulated in row-major order; cmp 0: raw sum, 1: sum == k*k (erosion), 2: sum >= 1.
+__global__ __launch_bounds__(256) void box_sum_cmp_kernel(const float* __restrict__ in, int H, int W, float* __restrict__ out, int Ho,
+                                                          int Wo, int k, int pad, int cmp) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Wo || y >= Ho) return;
+    float s = 0.f;
+    for (int dy = 0; dy < k; ++dy) {
+        const int yy = y - pad + dy;
+        for (int dx = 0; dx < k; ++dx) {
+            const int xx = x - pad + dx;
+            s = s + ((yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[(size_t)yy * W + xx] : 0.f);
+        }
+    }
+    float v = s;
+    if (cmp == 1) v = (s == (float)(k * k)) ? 1.f : 0.f;
+    else if (cmp == 2) v = (s >= 1.0f) ? 1.f : 0.f;
+    out[(size_t)y * Wo + x] = v;
+}
+
+extern "C" int st_box_sum_cmp(const float* in, int32_t H, int32_t W, float* out, int32_t Ho, int32_t Wo, int32_t k, int32_t pad,
+                              int32_t cmp, void* stream) {
+    if (!in || !out || in == out || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || k < 1 || pad < 0 || cmp < 0 || cmp > 2) return ST_EINVAL;
+    hipLaunchKernelGGL(box_sum_cmp_kernel, dim3((Wo + 63) / 64, (Ho + 3) / 4), dim3(256), 0, (hipStream_t)stream, in, H, W, out, Ho, Wo,
+                       k, pad, cmp);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// Elementwise stages.  Planes are [h*w]; "3" = three channel planes.  op:
+//  0 dilate_thin_area middle (utils.py:143-146): a = mask, b = dilation -> o0 = thick = clamp(a*b, 0, 1), o1 = thin = a*(1-thick)
+//  1 dilate_thin_area end (:158-159):           a = thick, b = dilated thin -> o0 = clamp(a + b, 0, 1), o1 = (o0 >= 1) (uint8 truncation
+//                                                of dilate_mask's to_pillow_fn, utils.py:165)
+//  2 threshold:                                  o0 = a > thr ? 1 : 0
+__global__ void mix_plane_op_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o0, float* __restrict__ o1,
+                                    size_t n, int op, float thr) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (op == 0) {
+        const float thick = fminf(fmaxf(a[p] * b[p], 0.f), 1.f);
+        o0[p] = thick; o1[p] = a[p] * (1.0f - thick);
+    } else if (op == 1) {
+        const float r = fminf(fmaxf(a[p] + b[p], 0.f), 1.f);
+        o0[p] = r; if (o1) o1[p] = (r >= 1.0f) ? 1.f : 0.f;
+    } else {
+        o0[p] = a[p] > thr ? 1.f : 0.f;
+    }
+}
+
+extern "C" int st_mix_plane_op(const float* a, const float* b, float* o0, float* o1, int64_t n, int32_t op, float thr, void* stream) {
+    if (!a || !o0 || n <= 0 || op < 0 || op > 2 || (op < 2 && !b) || (op == 0 && !o1)) return ST_EINVAL;
+    hipLaunchKernelGGL(mix_plane_op_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, o0, o1, (size_t)n, op, thr);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// stage A of both plug-ins (all_img1_with_inpaint.py:44-53 / inpaint_all_area.py:43-51): method 0 = all_img1_with_inpaint,
+// 1 = inpaint_all_area.  fw, m1, tps: 3 planes; occ, tmask: 1 plane -> tfw3, tfwm3, iam0 (channel 0 of the inpaint-area mask)
+__global__ void mix_stage_a_kernel(const float* __restrict__ fw, const float* __restrict__ occ, const float* __restrict__ m1,
+                                   const float* __restrict__ tps, const float* __restrict__ tmask, float* __restrict__ tfw,
+                                   float* __restrict__ tfwm, float* __restrict__ iam0, size_t hw, int method) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const float oc = occ[p], tm = tmask[p];
+    for (int c = 0; c < 3; ++c) {
+        const float m = m1[c * hw + p], f = fw[c * hw + p], t = tps[c * hw + p];
+        float a, am;
+        if (method == 0) {
+            const float inv = 1.0f - (m > 0.5f ? 1.0f : 0.0f);
+            a = f * oc * m + t * inv;
+            am = oc * m + tm * inv;
+        } else {
+            const float inv = 1.0f - m;
+            a = f * oc + t * inv;
+            am = oc + tm * inv;
+        }
+        tfw[c * hw + p] = a; tfwm[c * hw + p] = am;
+        if (c == 0) iam0[p] = method == 0 ? (1.0f - am) * m : (1.0f - am) * m * tm;
+    }
+}
+
+extern "C" int st_mix_stage_a(const float* final_warp3, const float* occ, const float* mask1_3, const float* tps3, const float* tmask,
+                              float* tfw3, float* tfwm3, float* iam0, int32_t h, int32_t w, int32_t method, void* stream) {
+    if (!final_warp3 || !occ || !mask1_3 || !tps3 || !tmask || !tfw3 || !tfwm3 || !iam0 || method < 0 || method > 1) return ST_EINVAL;
+    const size_t hw = (size_t)h * w;
+    hipLaunchKernelGGL(mix_stage_a_kernel, dim3((hw + 255) / 256), dim3(256), 0, (hipStream_t)stream, final_warp3, occ, mask1_3, tps3, tmask,
+                       tfw3, tfwm3, iam0, hw, method);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// all_img1_with_inpaint.py:58-70,77: iam (thin-area mask), dil (its 7x7 dilation, binary) ->
+//   border = |iam - dil|, by1 = (1 - border) * dil * mask1, only_img1 = tfw*(1-by1) + (output1*by1)*by1, other0 = (1 - by1_c0) * border
+__global__ void mix_stage_b_kernel(const float* __restrict__ iam, const float* __restrict__ dil, const float* __restrict__ m1,
+                                   const float* __restrict__ tfw, const float* __restrict__ o1, float* __restrict__ only_img1,
+                                   float* __restrict__ other0, size_t hw) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const float d = dil[p], border = fabsf(iam[p] - d);
+    for (int c = 0; c < 3; ++c) {
+        const float by1 = (1.0f - border) * d * m1[c * hw + p];
+        only_img1[c * hw + p] = tfw[c * hw + p] * (1.0f - by1) + (o1[c * hw + p] * by1) * by1;
+        if (c == 0) other0[p] = (1.0f - by1) * border;
+    }
+}
+
+extern "C" int st_mix_stage_b(const float* iam, const float* dil, const float* mask1_3, const float* tfw3, const float* output1_3,
+                              float* only_img1_3, float* other0, int32_t h, int32_t w, void* stream) {
+    if (!iam || !dil || !mask1_3 || !tfw3 || !output1_3 || !only_img1_3 || !other0) return ST_EINVAL;
+    const size_t hw = (size_t)h * w;
+    hipLaunchKernelGGL(mix_stage_b_kernel, dim3((hw + 255) / 256), dim3(256), 0, (hipStream_t)stream, iam, dil, mask1_3, tfw3, output1_3,
+                       only_img1_3, other0, hw);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// out3 = clip?(img3, 0, 255) * (inv ? 1 - mask : mask)    (all_img1_with_inpaint.py:82,85,101; clip for the control image)
+__global__ void mix_mul_mask_kernel(const float* __restrict__ img, const float* __restrict__ mask, float* __restrict__ out, size_t hw,
+                                    int inv, int clip, int use_mask) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const float m = use_mask ? (inv ? 1.0f - mask[p] : mask[p]) : 1.0f;
+    for (int c = 0; c < 3; ++c) {
+        float v = img[c * hw + p];
+        if (clip) v = fminf(fmaxf(v, 0.f), 255.f);
+        out[c * hw + p] = use_mask ? v * m : v;
+    }
+}
+
+extern "C" int st_mix_mul_mask(const float* img3, const float* mask, float* out3, int32_t h, int32_t w, int32_t invert, int32_t clip,
+                               void* stream) {
+    if (!img3 || !out3) return ST_EINVAL;
+    const size_t hw = (size_t)h * w;
+    hipLaunchKernelGGL(mix_mul_mask_kernel, dim3((hw + 255) / 256), dim3(256), 0, (hipStream_t)stream, img3, mask, out3, hw, invert, clip,
+                       mask ? 1 : 0);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// new_blend_image = clip((output1*mask1 + output2*mask2) / (mask1 + mask2), 0, 255) -> uint8 (tps_pipline.py:186-187);
+// mask2 has c2 (1 or 3) planes.
+__global__ void blend_pair_kernel(const float* __restrict__ o1, const float* __restrict__ m1, const float* __restrict__ o2,
+                                  const float* __restrict__ m2, int c2, unsigned char* __restrict__ blend, size_t hw) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    for (int c = 0; c < 3; ++c) {
+        const float mm2 = m2[(c2 == 3 ? c : 0) * hw + p], mm1 = m1[c * hw + p];
+        float bl = (o1[c * hw + p] * mm1 + o2[c * hw + p] * mm2) / (mm1 + mm2);
+        bl = fminf(fmaxf(bl, 0.0f), 255.0f);
+        blend[c * hw + p] = (bl == bl) ? (unsigned char)bl : (unsigned char)0;
+    }
+}
+
+extern "C" int st_blend_pair(const float* output1_3, const float* mask1_3, const float* output2_3, const float* mask2, int32_t mask2_planes,
+                             uint8_t* blend3, int32_t h, int32_t w, void* stream) {
+    if (!output1_3 || !mask1_3 || !output2_3 || !mask2 || !blend3 || (mask2_planes != 1 && mask2_planes != 3)) return ST_EINVAL;
+    const size_t hw = (size_t)h * w;
+    hipLaunchKernelGGL(blend_pair_kernel, dim3((hw + 255) / 256), dim3(256), 0, (hipStream_t)stream, output1_3, mask1_3, output2_3, mask2,
+                       mask2_planes, blend3, hw);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

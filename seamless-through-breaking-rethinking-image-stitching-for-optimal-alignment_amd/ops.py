@@ -513,3 +513,66 @@ def tps_mix_blend(tps3, inv_clean, final_warp3, output1_3, mask1_3):
     check(lib.st_tps_mix_blend(_pc(tps3), _pc(inv_clean), _pc(final_warp3), _pc(output1_3), _pc(mask1_3), _p(tmask), _p(mix),
                                _p(mixmask), _p(blend), H, W, _stream()), "st_tps_mix_blend")
     return tmask, mix, mixmask, blend
+
+
+# ---- mix_fn plug-ins (csrc/tps_pipeline.hip, second half) -----------------------------------------
+def box_sum_cmp(plane, k, pad, out_hw, cmp):
+    H, W = plane.shape[-2:]
+    out = torch.empty((1, 1, out_hw[0], out_hw[1]), device=plane.device, dtype=torch.float32)
+    check(lib.st_box_sum_cmp(_pc(plane), H, W, _p(out), out_hw[0], out_hw[1], k, pad, cmp, _stream()), "st_box_sum_cmp")
+    return out
+
+
+def dilate_thin_area_plane(mask0, dilation_kernel_size=8, thickening_kernel_size=8):
+    """core/inference/utils.py:125-160 on one plane [1,1,H,W] -> (result [1,1,H,W], result >= 1 as float)."""
+    H, W = mask0.shape[-2:]
+    k, p = dilation_kernel_size, dilation_kernel_size // 2
+    ho, wo = H + 2 * p - k + 1, W + 2 * p - k + 1
+    er = box_sum_cmp(mask0, k, p, (ho, wo), 1)
+    di = box_sum_cmp(er, k, p, (H, W), 2)
+    thick, thin = torch.empty_like(mask0), torch.empty_like(mask0)
+    check(lib.st_mix_plane_op(_pc(mask0), _pc(di), _p(thick), _p(thin), mask0.numel(), 0, 0.0, _stream()), "st_mix_plane_op")
+    k2, p2 = thickening_kernel_size, thickening_kernel_size // 2
+    dt = box_sum_cmp(thin, k2, p2, (H, W), 2)
+    res, ge1 = torch.empty_like(mask0), torch.empty_like(mask0)
+    check(lib.st_mix_plane_op(_pc(thick), _pc(dt), _p(res), _p(ge1), mask0.numel(), 1, 0.0, _stream()), "st_mix_plane_op")
+    return res, ge1
+
+
+def plane_threshold(a, thr):
+    out = torch.empty_like(a)
+    check(lib.st_mix_plane_op(_pc(a), None, _p(out), None, a.numel(), 2, float(thr), _stream()), "st_mix_plane_op")
+    return out
+
+
+def mix_stage_a(final_warp, occ, mask1, tps, tmask, method):
+    _, _, H, W = final_warp.shape
+    tfw, tfwm = torch.empty_like(final_warp), torch.empty_like(final_warp)
+    iam0 = torch.empty((1, 1, H, W), device=final_warp.device, dtype=torch.float32)
+    check(lib.st_mix_stage_a(_pc(final_warp), _pc(occ), _pc(mask1), _pc(tps), _pc(tmask), _p(tfw), _p(tfwm), _p(iam0), H, W, method,
+                             _stream()), "st_mix_stage_a")
+    return tfw, tfwm, iam0
+
+
+def mix_stage_b(iam, dil, mask1, tfw, output1):
+    _, _, H, W = tfw.shape
+    only1 = torch.empty_like(tfw)
+    other0 = torch.empty((1, 1, H, W), device=tfw.device, dtype=torch.float32)
+    check(lib.st_mix_stage_b(_pc(iam), _pc(dil), _pc(mask1), _pc(tfw), _pc(output1), _p(only1), _p(other0), H, W, _stream()),
+          "st_mix_stage_b")
+    return only1, other0
+
+
+def mix_mul_mask(img3, mask=None, invert=False, clip=False):
+    _, _, H, W = img3.shape
+    out = torch.empty_like(img3)
+    check(lib.st_mix_mul_mask(_pc(img3), _pc(mask) if mask is not None else None, _p(out), H, W, int(invert), int(clip), _stream()),
+          "st_mix_mul_mask")
+    return out
+
+
+def blend_pair(output1, mask1, output2, mask2):
+    _, _, H, W = output1.shape
+    blend = torch.empty((1, 3, H, W), device=output1.device, dtype=torch.uint8)
+    check(lib.st_blend_pair(_pc(output1), _pc(mask1), _pc(output2), _pc(mask2), mask2.shape[1], _p(blend), H, W, _stream()), "st_blend_pair")
+    return blend

@@ -11,8 +11,9 @@ Same call signature and result keys.  What runs where:
 Back-ends: ``tps_method="kornia"`` is the reference's in-tree back-end (pinned by tests/golden/tps_pipeline.npz).
 ``tps_method="opencv"`` (the shipped default) is served by the same kernels in pixel units: the exact r^2 log r^2
 interpolating spline that OpenCV's ThinPlateSplineShapeTransformer fits, sampled bilinearly -- OpenCV itself is not
-installable here, so that path is UNPINNED against OpenCV.  ``"other"`` and the inpainters (``inpaint_fn``) are out of
-scope: they raise NotImplementedError.
+installable here, so that path is UNPINNED against OpenCV.  ``"other"`` and the neural inpainters are out of
+scope.  ``inpaint_fn`` is the reference's ``mix_fn`` plug-in hook (out.py:235-236): `stitch_amd.mix_methods.<name>.mix_fn`
+restates both shipped mix methods on the GPU and takes any object with the reference's inpainter protocol.
 """
 from __future__ import annotations
 
@@ -140,8 +141,6 @@ def warp_by_tps(H_warp, H_warp_mask, points_src, points_dst, out_height, out_wid
 
 def tps_H_warp(inputs, image_limit, tps_pipeline_config, inpaint_fn=None, is_plot=False):
     """tps_pipline.py:20-205.  ``inputs`` / ``image_limit`` / config: objects or dicts with the reference's field names."""
-    if inpaint_fn is not None:
-        raise NotImplementedError("inpainters (core/inference/mix_methods/*) are out of scope: call with inpaint_fn=None")
     cfg = tps_pipeline_config
     dev = _get(inputs, "H_warp").device
     if dev.type != "cuda":
@@ -180,4 +179,15 @@ def tps_H_warp(inputs, image_limit, tps_pipeline_config, inpaint_fn=None, is_plo
         out.update(output2=tps, mask2=tmask)                                # :174-176 (tmask is binary: tps * tmask == tps)
     else:
         out.update(output2=mix, mask2=mixmask)
+    if inpaint_fn is not None:                                              # :178-188: the mix_fn plug-in (+ its inpainter)
+        assert _get(cfg, "output2_is_only_tps") is True
+        W, H = flow.shape[-1], flow.shape[-2]
+        width_max, height_max = out_w - abs(wmin), out_h - abs(hmin)
+        padding = (int(abs(wmin)), int(abs(width_max - W)), int(abs(hmin)), int(abs(height_max - H)))
+        tfw, tfwm, inpaint_img, inpaint_img_mask, inpaint_area_mask = inpaint_fn(
+            tps_H_warp=out["output2"].clone(), tps_H_warp_mask=out["mask2"].clone(), output1=output1, mask1=mask1,
+            final_warp=final_warp, occlusion_mask=g("occlusion_mask"), padding=padding, residual_flow=flow)
+        tfw, tfwm = tfw.float().contiguous(), tfwm.float().contiguous()
+        out.update(output2=tfw, mask2=tfwm, new_blend_image=ops.blend_pair(output1, mask1, tfw, tfwm),
+                   inpaint_img=inpaint_img, inpaint_area_mask=inpaint_area_mask)
     return out

@@ -259,3 +259,20 @@ def test_tps_pipeline_oracle_vs_reference_golden():
         assert np.array_equal(np.packbits((res["mask2"].numpy() >= 0.5).astype(np.uint8).reshape(-1)), g[f"pipe_{name}_mask2_bits"])
         assert np.array_equal(np.packbits((res["mix_tps_flow_warp_mask"].numpy() >= 0.5).astype(np.uint8).reshape(-1)),
                               g[f"pipe_{name}_mixmask_bits"])
+
+
+@pytest.mark.parametrize("mname", ["all_img1_with_inpaint", "inpaint_all_area"])
+def test_mix_methods_oracle_vs_reference_golden(mname):
+    """oracle restatement of the `mix_fn` plug-ins (core/inference/mix_methods/*.py) driven through tps_H_warp with a
+    pass-through inpainter, against the reference's own functions run the same way."""
+    from oracle import tps_pipeline as otp
+    g = np.load(os.path.join(GOLDEN, "tps_pipeline.npz"))
+    ih, iw, wmin, hmin, oh, ow = 200, 264, -21, -13, 236, 300
+    case = otp.synthetic_case(5, ih, iw, wmin, hmin, oh, ow)
+    fn = {"all_img1_with_inpaint": otp.mix_all_img1_with_inpaint, "inpaint_all_area": otp.mix_inpaint_all_area}[mname]
+    res = otp.tps_H_warp_with_inpaint(case, dict(width_min=wmin, height_min=hmin, out_height=oh, out_width=ow), _tps_cfg(), fn)
+    assert np.array_equal(res["new_blend_image"].numpy(), g[f"mix_{mname}_blend"])
+    assert np.array_equal(res["output2"][..., ::4, ::4].numpy(), g[f"mix_{mname}_output2_sub"])
+    assert np.array_equal(np.packbits((res["mask2"].numpy() >= 0.5).astype(np.uint8).reshape(-1)), g[f"mix_{mname}_mask2_bits"])
+    a = res["inpaint_area_mask"].double()
+    assert np.allclose([float(a.sum()), float((a * a).sum())], g[f"mix_{mname}_area_cs"], rtol=0, atol=0)

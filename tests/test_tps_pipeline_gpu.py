@@ -144,3 +144,61 @@ def test_opencv_mode_is_the_interpolating_spline(tp):
         assert out[0, 0, y, x] > 0.99, (x, y, out[0, 0, y, x])
     ident = ops.tps2_warp(img.cuda(), src[0], src[0], mode=1).cpu()
     assert (ident - img).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("mname", ["all_img1_with_inpaint", "inpaint_all_area"])
+def test_mix_methods_vs_oracle_and_reference_golden(tp, gold, mname):
+    """The `mix_fn` plug-ins through tps_H_warp(inpaint_fn=...) with the pass-through inpainter: masks and the filled image
+    follow the oracle (= the reference's own functions, golden `mix_*`); the uint8 blend inherits only the TPS-solve tolerance."""
+    import importlib
+    mix_fn = importlib.import_module(f"stitch_amd.mix_methods.{mname}").mix_fn
+    inp = importlib.import_module("stitch_amd.mix_methods.utils.passthrough_inpainter").inpainter
+    ih, iw, wmin, hmin, oh, ow = 200, 264, -21, -13, 236, 300
+    case = otp.synthetic_case(5, ih, iw, wmin, hmin, oh, ow)
+    limit = dict(width_min=wmin, height_min=hmin, out_height=oh, out_width=ow)
+    ofn = {"all_img1_with_inpaint": otp.mix_all_img1_with_inpaint, "inpaint_all_area": otp.mix_inpaint_all_area}[mname]
+    ref = otp.tps_H_warp_with_inpaint(case, limit, cfg(), ofn)
+    fn = lambda **kw: mix_fn(**kw, inpainter=inp, use_composition=False, is_plot=False, resize_to_area_limit_before_inpaint=750 * 750)  # noqa: E731
+    got = tp.tps_H_warp(cuda_case(case), SimpleNamespace(**limit), cfg(), inpaint_fn=fn)
+    mflips = int(((got["mask2"].cpu() >= 0.5) != (ref["mask2"] >= 0.5)).sum())
+    d = (got["output2"].cpu() - ref["output2"]).abs()
+    db = (got["new_blend_image"].cpu().int() - T(gold[f"mix_{mname}_blend"]).int()).abs()
+    da = (got["inpaint_area_mask"].cpu() - ref["inpaint_area_mask"]).abs()
+    print(f"[mix {mname}] mask2 flips {mflips}, output2 |d| max {d.max():.3e} p99 {np.percentile(d.numpy(), 99):.3e}, area-mask |d| max "
+          f"{da[:, -1].max():.1e}, blend: {(db > 0).float().mean():.2e} of bytes differ (max {int(db.max())})")
+    assert mflips <= 4 and da[:, -1].max() == 0                    # the binary "left to the inpainter" mask is exact
+    assert np.percentile(d.numpy(), 99) < 5e-2 and (db > 1).float().mean() < 2e-3
+
+
+def test_mix_stage_kernels_bit_exact():
+    """dilate_thin_area, the 7x7 dilate_mask and the elementwise stages on fractional masks: bit-exact vs the oracle."""
+    import stitch_amd
+    ops = stitch_amd.ops
+    g = torch.Generator().manual_seed(8)
+    h, w = 97, 141
+    m = (torch.rand(1, 1, h, w, generator=g) > 0.35).float()
+    m[:, :, 20:60, 30:100] = 1
+    m[:, :, 70:75, :] = torch.rand(1, 1, 5, w, generator=g)                         # fractional band
+    for tk in (8, 16):
+        res, ge1 = ops.dilate_thin_area_plane(m.cuda(), thickening_kernel_size=tk)
+        ref = otp.dilate_thin_area(m, thickening_kernel_size=tk)
+        assert torch.equal(res.cpu(), ref[:, 0:1]), tk
+        assert torch.equal(ops.rect_filter(ge1, 7, True).cpu(), (otp.dilate_mask(ref.repeat(1, 3, 1, 1), 7)[:, 0:1] > 0).float())
+    fw, tps, o1 = (torch.rand(1, 3, h, w, generator=g) * 255 for _ in range(3))
+    m1 = torch.rand(1, 3, h, w, generator=g).round() * (torch.rand(1, 3, h, w, generator=g) > 0.1) + 0.3 * (torch.rand(1, 3, h, w, generator=g) > 0.9)
+    m1 = m1.clip(0, 1)
+    occ, tm = (torch.rand(1, 1, h, w, generator=g) > 0.3).float(), (torch.rand(1, 1, h, w, generator=g) > 0.3).float()
+    for method in (0, 1):
+        tfw, tfwm, iam0 = ops.mix_stage_a(fw.cuda(), occ.cuda(), m1.cuda(), tps.cuda(), tm.cuda(), method)
+        if method == 0:
+            inv = 1. - (m1 > 0.5).float()
+            rt, rm = fw * occ * m1 + tps * inv, occ * m1 + tm * inv
+            ri = ((1. - rm) * m1)[:, 0:1]
+        else:
+            inv = 1. - m1
+            rt, rm = fw * occ + tps * inv, occ + tm * inv
+            ri = ((1. - rm) * m1 * tm)[:, 0:1]
+        assert torch.equal(tfw.cpu(), rt) and torch.equal(tfwm.cpu(), rm) and torch.equal(iam0.cpu(), ri)
+    bl = ops.blend_pair(o1.cuda(), m1.cuda(), tps.cuda(), tm.cuda()).cpu()
+    rb = torch.nan_to_num(((o1 * m1 + tps * tm) / (m1 + tm)).clip(0, 255), nan=0.0).to(torch.uint8)
+    assert torch.equal(bl, rb)
