@@ -269,7 +269,7 @@ int st_range_argmax(const float* grad, const int32_t* ranges, int32_t* out_flat_
 int st_gather_points(const float* planes, const int32_t* points_xy, float* out, int32_t n, int32_t P, int32_t H,
                      int32_t W, void* stream);
 /* TPS fit f(sites_i) = values_i, f(v) = a0 + [ax ay].v + sum_j w_j U(|v - centers_j|) -> kernel_w [n,2], affine_w [3,2];
- * work_f64: (n+3)*(n+5) doubles.  mode 0 = kornia get_tps_transform(points_src = sites, points_dst = centers = values) as
+ * work_f64: (n+3)*(n+6) doubles.  mode 0 = kornia get_tps_transform(points_src = sites, points_dst = centers = values) as
  * called by warp_by_tps (tps_pipline.py:362-378, kornia_tps.py:47-112): normalised points, U = 0.5 d2 log(d2 + 1e-8);
  * mode 1 = pixel-unit r^2 log r^2 spline with centers = sites (OpenCV ThinPlateSplineShapeTransformer's formulation,
  * opencv_tps.py:8-18).                                                                                                  */

@@ -463,7 +463,7 @@ def gather_points(planes, points_xy):
 def tps2_solve(sites, centers, values, mode=0):
     n = sites.shape[0]
     dev = sites.device
-    work = torch.empty(((n + 3) * (n + 5),), device=dev, dtype=torch.float64)
+    work = torch.empty(((n + 3) * (n + 6),), device=dev, dtype=torch.float64)
     kw = torch.empty((n, 2), device=dev, dtype=torch.float32)
     aw = torch.empty((3, 2), device=dev, dtype=torch.float32)
     check(lib.st_tps2_solve(_pc(sites), _pc(centers), _pc(values), _p(work), _p(kw), _p(aw), n, mode, _stream()), "st_tps2_solve")

@@ -127,6 +127,11 @@ def warp_by_tps(H_warp, H_warp_mask, points_src, points_dst, out_height, out_wid
                 is_plot=False):
     """tps_pipline.py:339-426 -> warped [1, 3 + C_mask, h, w] on the GPU."""
     x = torch.cat((H_warp, H_warp_mask), dim=1).float().contiguous()
+    if points_src.shape[1] < 3:
+        # fewer control points than the affine part of the spline has unknowns (every border sample was rejected by the flow
+        # limit / occlusion filter): the reference's solvers are singular here; leave the homography warp as it is
+        print(f"[tps_pipeline] only {points_src.shape[1]} control point(s) left: TPS warp skipped (identity)")
+        return x
     if tps_method == "kornia":
         ps, pd = points_src.to(torch.float64), points_dst.to(torch.float64)
         ps = torch.stack([ps[:, :, 0] / out_width, ps[:, :, 1] / out_height], 2).to(torch.float32)
