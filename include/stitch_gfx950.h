@@ -42,7 +42,8 @@ typedef struct st_gemm_desc {
     int32_t batch;         /* grid.z batches (0/1 = single)                                         */
     int64_t batch_stride_a, batch_stride_w, batch_stride_c;   /* in floats                          */
     int32_t tile_cfg;      /* 0 = auto; register-staged 1: 128x128, 2: 128x64, 3: 64x64, 4: 128x32;
-                              LDS-DMA pipelined (Cin % 32 == 0) 12: 128x64, 13: 64x64, 14: 128x32   */
+                              LDS-DMA pipelined (Cin % 32 == 0) 12: 128x64, 13: 64x64, 14: 128x32;
+                              row-streaming (plain matrix, K = 64 / 128) 20 */
     int32_t split_k;       /* 0 = auto, 1 = off, >1 = K slices (needs workspace, batch <= 1)        */
     float* workspace;      /* split-K slabs [split_k, M, N] or NULL (then never split)              */
     int64_t workspace_floats;
@@ -53,6 +54,11 @@ typedef struct st_gemm_desc {
     int64_t batch_stride_aux1;  /* floats; aux1 of batch z starts at aux1 + z * batch_stride_aux1          */
     int32_t dh, dw;        /* conv dilation (0 / 1 = dense): tap (ky,kx) reads pixel (oy*sh-ph+ky*dh, ox*sw-pw+kx*dw);
                               Ho / Wo are the caller's (PyTorch: H + 2*ph - dh*(kh-1) - 1) / sh + 1)            */
+    int32_t a_ln;          /* 1: every row of A is layer-normalised WITHOUT affine, (x - mean) * rstd over its K = Cin
+                              entries, before the contraction (nn.LayerNorm in front of a Linear, twins.py:787-790,
+                              encoder.py:156-172; the caller folds gamma into W and beta into the bias).  Row-streaming
+                              kernel only: plain matrix, K = 64 / 128, batch <= 1; anything else is rejected          */
+    float a_ln_eps;
 } st_gemm_desc;
 
 /* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.
@@ -69,7 +75,8 @@ int st_conv_gemm(const st_gemm_desc* desc, void* stream);
 int st_set_gemm_observer(void* callback, void* user);
 
 /* Profiling aid: the launch plan the library chose for the calling thread's most recent st_conv_gemm:
- *   plan4[0] kernel family (0 skinny_gemm, 1 narrow_conv, 2 conv_gemm_kernel [register-staged], 3 conv_gemm_dma_kernel)
+ *   plan4[0] kernel family (0 skinny_gemm, 1 narrow_conv, 2 conv_gemm_kernel [register-staged], 3 conv_gemm_dma_kernel,
+ *            4 rowstream_gemm_kernel)
  *   plan4[1] tile_cfg actually used, plan4[2] split_k actually used, plan4[3] 1 = persistent M walk.
  * Used by tools/gemm_shapes_csv.py to label every launch of a step (profiles/r2_gemm_shapes.csv). */
 int st_gemm_last_plan(int32_t* plan4);

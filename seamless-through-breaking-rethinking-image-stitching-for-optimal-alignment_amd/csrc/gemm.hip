@@ -42,7 +42,7 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsign
 // v = act(alpha*acc + bias[n] + aux0) followed by the combine mode; shared by the GEMM epilogue and
 // the split-K reducer.
 __device__ __forceinline__ float gemm_epilogue(const st_gemm_desc& d, int m, int n, float acc, float sc) {
-    float v = acc * d.alpha + (d.bias ? d.bias[n] : 0.f);
+    float v = fmaf(acc, d.alpha, d.bias ? d.bias[n] : 0.f);      // explicit fma everywhere: every kernel's epilogue rounds alike
     if (d.aux0) {
         int ar = m;
         if (d.aux0_row_div > 1) ar = m / d.aux0_row_div;
@@ -57,7 +57,7 @@ __device__ __forceinline__ float gemm_epilogue(const st_gemm_desc& d, int m, int
             const float z = d.aux1[(size_t)m * d.ld_aux1 + n], h = d.aux2[(size_t)m * d.ld_aux2 + n];
             v = (1.0f - z) * h + z * v;
         } break;
-        case ST_EPI_AXPY: v = d.aux1[(size_t)m * d.ld_aux1 + n] + sc * v; break;
+        case ST_EPI_AXPY: v = fmaf(sc, v, d.aux1[(size_t)m * d.ld_aux1 + n]); break;
         default: break;
     }
     return v;
@@ -68,7 +68,7 @@ __device__ __forceinline__ float gemm_epilogue(const st_gemm_desc& d, int m, int
 __device__ __forceinline__ void gemm_store(const st_gemm_desc& d, float* __restrict__ C, int m, int n, float acc, float sc) {
     if (d.epi == ST_EPI_ZR) {
         const int half = d.N >> 1;
-        float v = acc * d.alpha + (d.bias ? d.bias[n] : 0.f);
+        float v = fmaf(acc, d.alpha, d.bias ? d.bias[n] : 0.f);
         if (d.aux0) v += d.aux0[(size_t)m * d.ld_aux0 + n];
         v = st_act(v, d.act);
         if (n < half) C[(size_t)m * d.ldc + n] = v;
@@ -121,20 +121,26 @@ __device__ __forceinline__ void gemm_epilogue_consts(const st_gemm_desc& d, EpiO
     }
 }
 
-template <int TM, int TN>
+// LITE (row-streaming kernel; the host checks the descriptor): no per-element row mapping, no GRU / z|r modes -- their
+// operand registers and code are not instantiated.
+template <int TM, int TN, bool LITE = false>
 __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOperands<TM, TN>& e, int m0, int n0, int wm, int wn,
                                                    int li, int lh, int split) {
     const bool raw = split > 1;                                // raw partial sums: nothing to fetch
     const int half = d.N >> 1;
-    const bool zr = d.epi == ST_EPI_ZR;
+    const bool zr = !LITE && d.epi == ST_EPI_ZR;
     const long long M = d.M;
     // aux0 row = (m / div) % mod.  div == 8 without mod (one table row per pixel, 8 latent rows each -- the vertical
     // layers' q / k tables) keeps the SGPR-step form: a lane's rows m0' + (r&3) + 8*(r>>2), m0' % 4 == 0, map to
     // table rows m0'/8 + (r>>2), i.e. four loads.  Other mappings are computed per element (small GEMMs only).
+    // mod % 32 == 0 without div (a table of `mod` rows repeated down the matrix -- PatchEmbed's per-patch position table):
+    // a 32-row sub-tile never wraps, so it is the identity form started at row (sub-tile start) % mod.
     const bool div8 = d.aux0_row_div == 8 && d.aux0_row_mod <= 0;
-    const bool mapped = !div8 && (d.aux0_row_div > 1 || d.aux0_row_mod > 0);
+    const bool mod32 = d.aux0_row_div <= 1 && d.aux0_row_mod > 0 && (d.aux0_row_mod & 31) == 0;
+    const bool mapped = !LITE && !div8 && !mod32 && (d.aux0_row_div > 1 || d.aux0_row_mod > 0);
     const __amdgpu_buffer_rsrc_t r0 = epi_rsrc(raw ? nullptr : d.aux0, mapped ? 0x7fffffffLL
-                                               : div8 ? (((M + 7) / 8 - 1) * d.ld_aux0 + d.N) * 4 : ((M - 1) * d.ld_aux0 + d.N) * 4);
+                                               : div8 ? (((M + 7) / 8 - 1) * d.ld_aux0 + d.N) * 4
+                                               : mod32 ? ((long long)(d.aux0_row_mod - 1) * d.ld_aux0 + d.N) * 4 : ((M - 1) * d.ld_aux0 + d.N) * 4);
     const float* aux1 = d.aux1 ? d.aux1 + (size_t)(d.batch > 1 ? blockIdx.z : 0) * d.batch_stride_aux1 : nullptr;
     const __amdgpu_buffer_rsrc_t r1 = epi_rsrc((raw || d.epi == ST_EPI_STORE) ? nullptr : aux1, ((M - 1) * d.ld_aux1 + (zr ? half : d.N)) * 4);
     const __amdgpu_buffer_rsrc_t r2 = epi_rsrc((raw || d.epi != ST_EPI_GRU) ? nullptr : d.aux2, ((M - 1) * d.ld_aux2 + d.N) * 4);
@@ -164,7 +170,7 @@ __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOpe
 #pragma unroll
                     for (int r = 0; r < 16; ++r) e.a0[i][jn][r] = t4[r >> 2];
                 } else {
-                    const unsigned v0 = (unsigned)(row0 * d.ld_aux0 + nc) * 4u;
+                    const unsigned v0 = (unsigned)((mod32 ? row0 % d.aux0_row_mod : row0) * d.ld_aux0 + nc) * 4u;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) e.a0[i][jn][r] = buf_ld(r0, v0, (unsigned)(ST_EPI_ROW(r) * d.ld_aux0) * 4u);
                 }
@@ -174,7 +180,7 @@ __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOpe
                 const unsigned v1 = (unsigned)(row0 * d.ld_aux1 + c1) * 4u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) e.x1[i][jn][r] = buf_ld(r1, v1, (unsigned)(ST_EPI_ROW(r) * d.ld_aux1) * 4u);
-                if (d.epi == ST_EPI_GRU) {
+                if (!LITE && d.epi == ST_EPI_GRU) {
                     const unsigned v2 = (unsigned)(row0 * d.ld_aux2 + nc) * 4u;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) e.x2[i][jn][r] = buf_ld(r2, v2, (unsigned)(ST_EPI_ROW(r) * d.ld_aux2) * 4u);
@@ -184,7 +190,7 @@ __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOpe
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool LITE = false>
 __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN],
                                                     const EpiOperands<TM, TN>& e, int m0, int n0, int wm, int wn, int li, int lh,
                                                     int split, int kz) {
@@ -205,7 +211,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float
         }
         return;
     }
-    const bool zr = d.epi == ST_EPI_ZR;
+    const bool zr = !LITE && d.epi == ST_EPI_ZR;
     const __amdgpu_buffer_rsrc_t rc = epi_rsrc(C, ((M - 1) * d.ldc + (zr ? half : d.N)) * 4);
     const __amdgpu_buffer_rsrc_t rc2 = epi_rsrc(zr ? d.c2 : nullptr, ((M - 1) * d.ldc2 + half) * 4);
 #pragma unroll
@@ -217,7 +223,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float
             const int row0 = m0 + wm * TM * 32 + i * 32 + 4 * lh;
             float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[i][jn][r] * d.alpha + e.bv[jn];
+            for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[i][jn][r], d.alpha, e.bv[jn]);
             if (d.aux0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] += e.a0[i][jn][r];
@@ -260,8 +266,8 @@ __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float
                         const float x1 = e.x1[i][jn][r];
                         float o = v[r] + x1;                                   // ST_EPI_ADD
                         if (d.epi == ST_EPI_MUL) o = v[r] * x1;
-                        else if (d.epi == ST_EPI_GRU) o = (1.0f - x1) * e.x2[i][jn][r] + x1 * v[r];
-                        else if (d.epi == ST_EPI_AXPY) o = x1 + e.sc * v[r];
+                        else if (!LITE && d.epi == ST_EPI_GRU) o = (1.0f - x1) * e.x2[i][jn][r] + x1 * v[r];
+                        else if (d.epi == ST_EPI_AXPY) o = fmaf(e.sc, v[r], x1);
                         buf_st(o, rc, vc, (unsigned)(ST_EPI_ROW(r) * d.ldc) * 4u);
                     }
                 }
@@ -808,6 +814,141 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     if (!PERSIST) gemm_epilogue_store<TM, TN>(d, C, acc, eop, m0, n0, wm, wn, li, lh, split, kz);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-streaming GEMM for the short-K linears (K = 64 / 128: the Twins / latent / vertical-layer linears at
+// M = 32768 ... 524288: twins.py:253-304,336-392,785, encoder.py:156-172, crossattentionlayer.py:37-56).  Those shapes are
+// MFMA-bound and HBM-bound at once (64 MFMAs per 64x64 tile against 48 KB of traffic), so the tiled kernels pay for
+// every barrier and for fetching A once per column tile.  Here:
+//   - the weight slice of the workgroup (<= 8 chunks of 32 columns x K) is staged into LDS ONCE and stays there
+//     ([n][K + 4] padded rows: the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads), with its bias;
+//   - a wave owns whole 32-row blocks of A and keeps a block in REGISTERS (K / 2 floats per lane, loaded straight from
+//     global memory with 16-byte buffer loads; lane (li, lh) holds k = 8j + 4lh + t of row li -- the same k pairing and
+//     the same summation order as the tiled kernels, so results are bit-identical to theirs); for K <= 128 the next
+//     block is prefetched under the MFMAs of the current one (in two halves, each issued AFTER the epilogue operand
+//     loads of its chunk: vmcnt retires in order, so an epilogue must never have to wait for the prefetch);
+//   - so the main loop has no barrier, no LDS traffic for A, and each wave runs independently: for every 32-column
+//     chunk, K/2 MFMAs fed by K/8 ds_read_b128, then the shared epilogue (a half-chunk start delay for waves 4-7, so
+//     that the two waves of a SIMD do not run their epilogues side by side, was measured neutral to slightly worse);
+//   - because a lane pair holds a complete row, LayerNorm of the A rows (d.a_ln) is two in-register reductions and one
+//     cross-half exchange: the LayerNorm kernel in front of these linears, its write and its re-read disappear.
+// Column slices (more chunks than a workgroup keeps, or too few row blocks to give every wave one) are separate
+// workgroups that walk the same rows; the slices of a row group get block ids that land on the same XCD (shared L2).
+template <int KC, bool PREFETCH>
+__global__ __launch_bounds__(512) void rowstream_gemm_kernel(const st_gemm_desc d, const int chunks_per_slice, const int nslices) {
+    constexpr int K = 32 * KC, LDW = K + 4, NJ = 4 * KC, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int S = nslices, G = (int)gridDim.x / S;
+    const int q = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+    const int sl = q % S, g = (q / S) * 8 + xcd;                 // slice, workgroup index inside the slice (0 .. G-1)
+    const int n_base = sl * chunks_per_slice * 32;
+    const int ncols = min(d.N - n_base, chunks_per_slice * 32);
+    const int nch = (ncols + 31) >> 5;
+    const int nblk = (d.M + 31) >> 5;
+    const int stride = G * NW;
+    float* bias_lds = smem + chunks_per_slice * 32 * LDW;
+
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.a), 0, (int)d.a_bytes, 0x00020000);
+    auto row_off = [&](int blk) {
+        const int row = blk * 32 + li;
+        return (blk < nblk && row < d.M) ? (unsigned)(row * d.ldx + 4 * lh) * 4u : ST_OOB;
+    };
+    int blk = g * NW + wave;
+    float4 a[NJ], an[PREFETCH ? NJ : 1];
+    {
+        const unsigned off = row_off(blk);                       // in flight while the weight slice is staged
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a[j] = buf_load16(rsrcA, off + 32u * j);
+    }
+    {
+        // weight slice -> LDS, 8 float4 per thread in flight at a time
+        const int total = nch * 32 * (K / 4);
+        for (int f0 = 0; f0 < total; f0 += 512 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int f = f0 + u * 512 + tid, r = f / (K / 4), c4 = f - r * (K / 4);
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < total && r < ncols) v[u] = *reinterpret_cast<const float4*>(d.w + (size_t)(n_base + r) * d.ldw + c4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int f = f0 + u * 512 + tid, r = f / (K / 4), c4 = f - r * (K / 4);
+                if (f < total) *reinterpret_cast<float4*>(smem + r * LDW + c4 * 4) = v[u];
+            }
+        }
+        if (tid < nch * 32) bias_lds[tid] = (d.bias && tid < ncols) ? d.bias[n_base + tid] : 0.f;
+    }
+    const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
+    __syncthreads();
+
+    const float* wl = smem + li * LDW + 4 * lh;
+    EpiOperands<1, 1> e;
+    e.sc = sc;
+    for (; blk < nblk; blk += stride) {
+        const int m0 = blk * 32;
+        const unsigned noff = PREFETCH ? row_off(blk + stride) : 0u;
+        if (d.a_ln) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) s += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+            s += __shfl_xor(s, 32, 64);
+            const float mean = s * (1.0f / K);
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                a[j].x -= mean; a[j].y -= mean; a[j].z -= mean; a[j].w -= mean;
+                v += (a[j].x * a[j].x + a[j].y * a[j].y) + (a[j].z * a[j].z + a[j].w * a[j].w);
+            }
+            v += __shfl_xor(v, 32, 64);
+            const float rstd = 1.0f / sqrtf(v * (1.0f / K) + d.a_ln_eps);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { a[j].x *= rstd; a[j].y *= rstd; a[j].z *= rstd; a[j].w *= rstd; }
+        }
+        for (int c = 0; c < nch; ++c) {
+            const int n0 = n_base + c * 32;
+            e.bv[0] = bias_lds[c * 32 + li];
+            gemm_epilogue_load<1, 1, true>(d, e, m0, n0, 0, 0, li, lh, 1);
+            if (PREFETCH) {
+                if (c == 0) {
+#pragma unroll
+                    for (int j = 0; j < NJ / 2; ++j) an[j] = buf_load16(rsrcA, noff + 32u * j);
+                }
+                if (c == 1 || nch == 1) {
+#pragma unroll
+                    for (int j = NJ / 2; j < NJ; ++j) an[PREFETCH ? j : 0] = buf_load16(rsrcA, noff + 32u * j);
+                }
+            }
+            f32x16 acc[1][1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+            const float* wb = wl + c * 32 * LDW;
+            float4 b = *reinterpret_cast<const float4*>(wb);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                // the fragment of step j+1 is read under the MFMAs of step j
+                const float4 bn = *reinterpret_cast<const float4*>(wb + 8 * (j + 1 < NJ ? j + 1 : j));
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b.x, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b.y, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b.z, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b.w, acc[0][0], 0, 0, 0);
+                b = bn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            gemm_epilogue_store<1, 1, true>(d, d.c, acc, e, m0, n0, 0, 0, li, lh, 1, 0);
+        }
+        if (PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) a[j] = an[j];
+        } else if (blk + stride < nblk) {
+            const unsigned off = row_off(blk + stride);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) a[j] = buf_load16(rsrcA, off + 32u * j);
+        }
+    }
+}
+
 // split-K tail: sum the K-slice slabs [split][M][N] in slice order (deterministic) + epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const st_gemm_desc d) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -944,6 +1085,32 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
     return ST_OK;
 }
 
+// row-streaming kernel: S column slices of `cps` 32-column chunks, G workgroups (512 threads, one per CU) per slice.
+// S is the smallest power of two that (a) keeps a slice within `max_cps` chunks and (b) yields at least one (row block,
+// slice) item per wave of the chip; G * S = 256, G a multiple of 8 (one run of workgroups per XCD).
+template <int KC>
+static int launch_rowstream(const st_gemm_desc& d, int max_cps, hipStream_t s) {
+    const int nchunks = (d.N + 31) / 32;
+    const int nblk = (d.M + 31) / 32;
+    const int lds_cap = (160 * 1024 - 1024) / (32 * (32 * KC + 4) * 4);
+    if (max_cps > lds_cap) max_cps = lds_cap;
+    int S = 1;
+    while (S < 32 && ((nchunks + S - 1) / S > max_cps || ((long)nblk * S < 2048 && 2 * S <= nchunks))) S *= 2;
+    const int cps = (nchunks + S - 1) / S;
+    if (cps > lds_cap) return ST_EINVAL;
+    S = (nchunks + cps - 1) / cps;                 // drop empty slices ...
+    int G = (256 / S) / 8 * 8;                      // ... (G * S <= 256)
+    if (G < 8) G = 8;
+    const int need = ((nblk + 7) / 8 + 7) / 8 * 8;
+    if (G > need) G = need;
+    const size_t lds = ((size_t)cps * 32 * (32 * KC + 4) + cps * 32) * sizeof(float);
+    auto k = rowstream_gemm_kernel<KC, true>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(G * S), dim3(512), lds, s, d, cps, S);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     st_gemm_desc d = *desc;
     if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
@@ -1026,6 +1193,26 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         hipLaunchKernelGGL(narrow_conv_kernel<4>, dim3((d.M + 3) / 4), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;
+    }
+    {
+        // row-streaming kernel (weights resident in LDS, A rows in registers): plain matrices with K = 64 / 128 and enough
+        // 32-row blocks to give every wave of the chip at least one
+        const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && (int64_t)d.H * d.W == d.M;
+        const bool map_ok = (d.aux0_row_div <= 1 && (d.aux0_row_mod <= 0 || d.aux0_row_mod % 32 == 0)) ||
+                            (d.aux0_row_div == 8 && d.aux0_row_mod <= 0) || !d.aux0;
+        const bool rs_ok = plain && aligned && batch == 1 && d.split_k <= 1 && (d.K == 64 || d.K == 128) &&
+                           d.epi != ST_EPI_ZR && d.epi != ST_EPI_GRU && map_ok;
+        // measured on MI355X, in the pipeline and stand-alone (tools/rowstream_bench.py): ahead of the LDS-DMA kernel for K = 64,
+        // for M >= 262144 and for N >= 384; behind it by ~2 us per launch at M <= 65536, N = 128 (one block per wave: all
+        // start-up); K = 256 (no room for the prefetch) was 10-30 % slower everywhere and is not instantiated
+        const bool rs_want = d.tile_cfg == 20 || (d.tile_cfg == 0 && d.M >= 16384 &&
+                                                  (d.K == 64 || d.M >= 262144 || (d.N >= 384 && d.M >= 32768)));
+        if (d.a_ln && !(rs_ok && (d.tile_cfg == 0 || d.tile_cfg == 20))) return ST_EINVAL;
+        if (rs_ok && (rs_want || d.a_ln)) {
+            g_last_plan[0] = 4; g_last_plan[1] = 20; g_last_plan[2] = 1; g_last_plan[3] = 1;
+            return d.K == 64 ? launch_rowstream<2>(d, 8, s) : launch_rowstream<4>(d, 8, s);
+        }
+        if (d.tile_cfg >= 20) return ST_EINVAL;
     }
     // tile choice: largest tile that still yields >= ~1.5 waves of workgroups over the 256 CUs
     auto nwg = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };

@@ -17,12 +17,19 @@ Design notes (MI355X-first, not a translation):
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
 from .checkpoint import HP, ParamTree, flat_params, flow_spec
 from .homography import pack_conv
+
+
+# LayerNorm in front of a K = 128 Linear runs inside the row-streaming GEMM (ops.conv_gemm(ln_eps=...)): gamma / beta are
+# folded into the weights at pack time.  ST_FUSE_LN=0 keeps the separate LayerNorm kernel (A/B measurements).
+FUSE_LN = os.environ.get("ST_FUSE_LN", "1") != "0"
 
 
 def _new(rows, cols, dev, zero=False):
@@ -74,11 +81,16 @@ class FlowFormer(ParamTree):
                                   fc1=lin(b0 + "mlp.fc1"), fc2=lin(b0 + "mlp.fc2"),
                                   # a zero-padded token's q/k/v is the bias (twins.py:606-611)
                                   pads=tuple(qkv_b[i * C:(i + 1) * C].expand(49, C).contiguous() for i in range(3)))
+                if C == 128:
+                    t[f"l{s}"]["qkv_ln"] = ops.fold_layernorm(*t[f"l{s}"]["n1"], qkv_w, qkv_b)
+                    t[f"l{s}"]["fc1_ln"] = ops.fold_layernorm(*t[f"l{s}"]["n2"], *t[f"l{s}"]["fc1"])
                 w9 = p[prefix + f"pos_block.{s}.proj.0.weight"].reshape(C, 9).t().contiguous()
                 t[f"peg{s}"] = (w9, p[prefix + f"pos_block.{s}.proj.0.bias"].contiguous())
                 t[f"g{s}"] = dict(n1=lin(b1 + "norm1"), q=lin(b1 + "attn.q"), kv=lin(b1 + "attn.kv"), sr=conv(b1 + "attn.sr"),
                                   srn=lin(b1 + "attn.norm"), proj=lin(b1 + "attn.proj"), n2=lin(b1 + "norm2"),
                                   fc1=lin(b1 + "mlp.fc1"), fc2=lin(b1 + "mlp.fc2"))
+                if C == 128:
+                    t[f"g{s}"]["fc1_ln"] = ops.fold_layernorm(*t[f"g{s}"]["n2"], *t[f"g{s}"]["fc1"])
             return t
 
         pk["fnet"] = twins("memory_encoder.feat_encoder.svt.")
@@ -98,7 +110,9 @@ class FlowFormer(ParamTree):
                      f3=lin(name + ".ffn.3"), q=lin(name + ".q"))
             if fuse_qkv:
                 d["qkv"] = cat_lin([name + ".q", name + ".k", name + ".v"])
+                d["qkv_ln"] = ops.fold_layernorm(*d["n1"], *d["qkv"])
             d["kv"] = cat_lin([name + ".k", name + ".v"])
+            d["f0_ln"] = ops.fold_layernorm(*d["n2"], *d["f0"])
             return d
         pk["xin"] = attn_layer(c + "input_layer", False)
         # first layer: the queries are the (normalised, projected) latent tokens themselves -- constants of the weights.
@@ -136,6 +150,9 @@ class FlowFormer(ParamTree):
                 gskb=p[gb + "attn.sr_key.bias"].contiguous(), gsv=conv(gb + "attn.sr_value")))
             vert[-1]["lqkv"] = torch.cat([vert[-1]["lq"][0][:, :128], vert[-1]["lk"][0][:, :128], vert[-1]["lv"][0]], 0).contiguous()
             vert[-1]["gskv"] = torch.cat([vert[-1]["gskx"], vert[-1]["gsv"][0]], 0).contiguous()   # sr_key (x part) | sr_value
+            vert[-1]["lqkv_ln"] = ops.fold_layernorm(*vert[-1]["ln1"], vert[-1]["lqkv"])
+            vert[-1]["lfc1_ln"] = ops.fold_layernorm(*vert[-1]["ln2"], *vert[-1]["lfc1"])
+            vert[-1]["gfc1_ln"] = ops.fold_layernorm(*vert[-1]["gn2"], *vert[-1]["gfc1"])
         pk["vert"] = vert
         m = "memory_decoder."
         Q = HP["query_latent_dim"]
@@ -184,12 +201,15 @@ class FlowFormer(ParamTree):
 
     # ================================================================== shared blocks
     @staticmethod
-    def _mlp(x, n2, fc1, fc2, eps, out=None):
+    def _mlp(x, n2, fc1, fc2, eps, out=None, fc1_ln=None):
         dev = x.device
-        y = _new(x.shape[0], x.shape[1], dev)
-        ops.layernorm(x, n2[0], n2[1], y, eps)
         h = _new(x.shape[0], fc1[0].shape[0], dev)
-        ops.conv_gemm(y, fc1[0], h, bias=fc1[1], act="gelu")
+        if fc1_ln is not None and FUSE_LN:
+            ops.conv_gemm(x, fc1_ln[0], h, bias=fc1_ln[1], act="gelu", ln_eps=eps)
+        else:
+            y = _new(x.shape[0], x.shape[1], dev)
+            ops.layernorm(x, n2[0], n2[1], y, eps)
+            ops.conv_gemm(y, fc1[0], h, bias=fc1[1], act="gelu")
         o = _new(x.shape[0], x.shape[1], dev) if out is None else out
         ops.conv_gemm(h, fc2[0], o, bias=fc2[1], aux0=x)
         return o
@@ -210,15 +230,18 @@ class FlowFormer(ParamTree):
             # ---- LSA block (twins.py:587-631)
             L = t[f"l{s}"]
             y = _new(N, C, dev)
-            ops.layernorm(x, L["n1"][0], L["n1"][1], y, 1e-6)
             qkv = _new(N, 3 * C, dev)
-            ops.conv_gemm(y, L["qkv"][0], qkv, bias=L["qkv"][1])
+            if "qkv_ln" in L and FUSE_LN:
+                ops.conv_gemm(x, L["qkv_ln"][0], qkv, bias=L["qkv_ln"][1], ln_eps=1e-6)
+            else:
+                ops.layernorm(x, L["n1"][0], L["n1"][1], y, 1e-6)
+                ops.conv_gemm(y, L["qkv"][0], qkv, bias=L["qkv"][1])
             att = _new(N, C, dev)
             ops.window_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], H * W * 3 * C, 3 * C, *L["pads"], att,
                                  H * W * C, C, B, H, W, hd, C // hd, 7, (C // hd) ** -0.5)
             x1 = _new(N, C, dev)
             ops.conv_gemm(att, L["proj"][0], x1, bias=L["proj"][1], aux0=x)
-            x2 = self._mlp(x1, L["n2"], L["fc1"], L["fc2"], 1e-6)
+            x2 = self._mlp(x1, L["n2"], L["fc1"], L["fc2"], 1e-6, fc1_ln=L.get("fc1_ln"))
             # ---- PEG (twins.py:793-808)
             x3 = _new(N, C, dev)
             ops.dwconv3x3_residual(x2, t[f"peg{s}"][0], t[f"peg{s}"][1], x3, B, H, W, C)
@@ -239,7 +262,7 @@ class FlowFormer(ParamTree):
                                 (H * W * C, C), B, hd, H * W, Nk, C // hd, (C // hd) ** -0.5)
             x4 = _new(N, C, dev)
             ops.conv_gemm(att, Gk["proj"][0], x4, bias=Gk["proj"][1], aux0=x3)
-            x = self._mlp(x4, Gk["n2"], Gk["fc1"], Gk["fc2"], 1e-6)
+            x = self._mlp(x4, Gk["n2"], Gk["fc1"], Gk["fc2"], 1e-6, fc1_ln=Gk.get("fc1_ln"))
         return x, H, W
 
     # ------------------------------------------------------------------ cost-volume encoder
@@ -293,10 +316,13 @@ class FlowFormer(ParamTree):
             x1 = _new(M * nl, 128, dev)
             ops.conv_gemm(att, L["proj"][0], x1, bias=proj_b, aux0=lat, row_mod=nl)
         else:
-            y = _new(M * nl, 128, dev)
-            ops.layernorm(x, L["n1"][0], L["n1"][1], y, 1e-5)
             qkv = _new(M * nl, 384, dev)
-            ops.conv_gemm(y, L["qkv"][0], qkv, bias=L["qkv"][1])
+            if FUSE_LN:
+                ops.conv_gemm(x, L["qkv_ln"][0], qkv, bias=L["qkv_ln"][1], ln_eps=1e-5)
+            else:
+                y = _new(M * nl, 128, dev)
+                ops.layernorm(x, L["n1"][0], L["n1"][1], y, 1e-5)
+                ops.conv_gemm(y, L["qkv"][0], qkv, bias=L["qkv"][1])
             att = _new(M * nl, 128, dev)
             ops.attention_small(qkv[:, :128], (nl * 384, 384), qkv[:, 128:256], (nl * 384, 384), qkv[:, 256:], (nl * 384, 384),
                                 att, (nl * 128, 128), M, 8, nl, nl, 16, 16 ** -0.5)
@@ -307,10 +333,13 @@ class FlowFormer(ParamTree):
     @staticmethod
     def _mlp_plain(x, L):
         dev = x.device
-        y = _new(x.shape[0], x.shape[1], dev)
-        ops.layernorm(x, L["n2"][0], L["n2"][1], y, 1e-5)
         h = _new(x.shape[0], L["f0"][0].shape[0], dev)
-        ops.conv_gemm(y, L["f0"][0], h, bias=L["f0"][1], act="gelu")
+        if FUSE_LN:
+            ops.conv_gemm(x, L["f0_ln"][0], h, bias=L["f0_ln"][1], act="gelu", ln_eps=1e-5)
+        else:
+            y = _new(x.shape[0], x.shape[1], dev)
+            ops.layernorm(x, L["n2"][0], L["n2"][1], y, 1e-5)
+            ops.conv_gemm(y, L["f0"][0], h, bias=L["f0"][1], act="gelu")
         o = _new(x.shape[0], x.shape[1], dev)
         ops.conv_gemm(h, L["f3"][0], o, bias=L["f3"][1], aux0=x)
         return o
@@ -325,7 +354,8 @@ class FlowFormer(ParamTree):
         Cq = C + Cc
         # ---------------- local block
         y = _new(R, C, dev)
-        ops.layernorm(x, V["ln1"][0], V["ln1"][1], y, 1e-5)
+        if not FUSE_LN:
+            ops.layernorm(x, V["ln1"][0], V["ln1"][1], y, 1e-5)
         z = _new(B * N, Cq, dev, zero=True)
         ops.conv_gemm(ctx, V["lctx"][0], z[:, C:], bias=V["lctx"][1])
         ops.sine_pe(z, Cq, Wg=W1, ws=7, period=N, accumulate=True)          # window-local code (twins.py:285-288)
@@ -335,7 +365,10 @@ class FlowFormer(ParamTree):
         ops.conv_gemm(z, V["lq"][0], T[:, :C], bias=V["lq"][1])
         ops.conv_gemm(z, V["lk"][0], T[:, C:2 * C], bias=V["lk"][1])
         qkv = _new(R, 3 * C, dev)
-        ops.conv_gemm(y, V["lqkv"], qkv, aux0=T, row_div=nl)
+        if FUSE_LN:
+            ops.conv_gemm(x, V["lqkv_ln"][0], qkv, bias=V["lqkv_ln"][1], aux0=T, row_div=nl, ln_eps=1e-5)
+        else:
+            ops.conv_gemm(y, V["lqkv"], qkv, aux0=T, row_div=nl)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         key = ("lsa_pad", id(V))
         if key not in self._const:
@@ -353,7 +386,7 @@ class FlowFormer(ParamTree):
                                  16 ** -0.5)
         x1 = _new(R, C, dev)
         ops.conv_gemm(att, V["lproj"][0], x1, bias=V["lproj"][1], aux0=x)
-        x2 = self._mlp(x1, V["ln2"], V["lfc1"], V["lfc2"], 1e-5)
+        x2 = self._mlp(x1, V["ln2"], V["lfc1"], V["lfc2"], 1e-5, fc1_ln=V["lfc1_ln"])
         # ---------------- global block
         ops.layernorm(x2, V["gn1"][0], V["gn1"][1], y, 1e-5)
         z = _new(B * N, Cq, dev, zero=True)
@@ -395,7 +428,7 @@ class FlowFormer(ParamTree):
                                 att[sl], (C, nl * C), nl, 8, N, Nk, 16, 16 ** -0.5)
         x3 = _new(R, C, dev)
         ops.conv_gemm(att, V["gproj"][0], x3, bias=V["gproj"][1], aux0=x2)
-        return self._mlp(x3, V["gn2"], V["gfc1"], V["gfc2"], 1e-5)
+        return self._mlp(x3, V["gn2"], V["gfc1"], V["gfc2"], 1e-5, fc1_ln=V["gfc1_ln"])
 
     def _cost_encoder(self, cost_maps, ctx, B, H1, W1):
         """CostPerceiverEncoder.forward (encoder.py:258-287) -> cost memory rows [B*N*8, 128]."""

@@ -74,8 +74,12 @@ class workspace_scope:
 
 
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
-              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, dil=(1, 1), M=None, tile=0, split_k=0, out2=None):
+              epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, dil=(1, 1), M=None, tile=0, split_k=0, out2=None,
+              ln_eps=None):
     """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
+
+    ln_eps: the rows of x are layer-normalised (no affine: fold gamma / beta into w / bias, ``fold_layernorm``) inside
+    the kernel before the product (row-streaming kernel only: plain matrix, K = 64 / 128).
 
     x: 2-D view [rows, Cin] of a channels-last activation; geom=(B,H,W,kh,kw,sh,sw,ph,pw) or None (1x1).
     w: [N, kh*kw*Cin] view.  out/aux*: 2-D views (column slices of wider buffers are fine)."""
@@ -112,6 +116,8 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     d.dh, d.dw = dil
     d.tile_cfg = tile
     d.split_k = split_k
+    if ln_eps is not None:
+        d.a_ln, d.a_ln_eps = 1, float(ln_eps)
     if out2 is not None:
         d.c2, d.ldc2 = out2.data_ptr(), _ld(out2)
     if batch <= 1 and split_k != 1:
@@ -119,6 +125,19 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
         d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     check(lib.st_conv_gemm(C.byref(d), _stream()), "st_conv_gemm")
     return out
+
+
+def fold_layernorm(gamma, beta, w, bias=None):
+    """Weights of ``Linear(LayerNorm(x))`` with the affine folded in, so that the GEMM can normalise its A rows in
+    registers (``ln_eps=``): W' = W * gamma (per input column), b' = b + W @ beta.  Weight-only constant folding at
+    load time, fp64 on the host."""
+    dev = w.device
+    w64, g64, b64 = w.detach().double().cpu(), gamma.detach().double().cpu(), beta.detach().double().cpu()
+    wf = (w64 * g64[None, :]).float().contiguous().to(dev)
+    bf = w64 @ b64
+    if bias is not None:
+        bf = bf + bias.detach().double().cpu()
+    return wf, bf.float().contiguous().to(dev)
 
 
 def corr_volume(f1, f2, out):

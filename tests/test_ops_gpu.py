@@ -642,3 +642,76 @@ def test_latent_pool(ops, M, P):
     z = torch.empty(M * 64, 128, device="cuda")
     ops.latent_pool(Sw[:, 4:68], dev(T_), z, M, P)
     assert (z.cpu().double().view(M, 64, 128) - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(70001, 130, 128, "res"), (65536, 384, 128, "div8"), (40000, 128, 64, "mod64"), (33, 512, 128, "gelu"),
+                                        (300000, 64, 128, "none"), (4100, 96, 64, "axpy")])
+def test_gemm_rowstream(ops, M, N, K, mode):
+    """row-streaming kernel (weights resident in LDS, A rows in registers; tile 20): every epilogue form it accepts, ragged M and N,
+    column-slice operands; bit-identical to the register-staged kernel (same k pairing and summation order)."""
+    xw = torch.randn(M, K + 32, generator=g(1))
+    x = dev(xw)[:, 16:16 + K]
+    w, b = torch.randn(N, K, generator=g(2)) / K ** 0.5, torch.randn(N, generator=g(3))
+    kw, ref = dict(bias=dev(b)), F.linear(xw[:, 16:16 + K].double(), w.double(), b.double())
+    if mode == "res":
+        res = torch.randn(M, N, generator=g(4))
+        kw.update(aux0=dev(res), act="relu")
+        ref = F.relu(ref + res.double())
+    elif mode == "div8":
+        tab = torch.randn((M + 7) // 8, N, generator=g(4))
+        kw.update(aux0=dev(tab), row_div=8)
+        ref = ref + tab.double()[torch.arange(M) // 8]
+    elif mode == "mod64":
+        tab = torch.randn(64, N, generator=g(4))
+        kw.update(aux0=dev(tab), row_mod=64, act="relu")
+        ref = F.relu(ref + tab.double()[torch.arange(M) % 64])
+    elif mode == "gelu":
+        kw.update(act="gelu")
+        ref = F.gelu(ref)
+    elif mode == "axpy":
+        h, gam = torch.randn(M, N, generator=g(4)), torch.tensor([0.37])
+        kw.update(epi="axpy", aux1=dev(h), scale_ptr=dev(gam), alpha=0.5)
+        ref = h.double() + 0.37 * (0.5 * F.linear(xw[:, 16:16 + K].double(), w.double()) + b.double())
+    out = torch.full((M, N + 8), 7.0, device="cuda")
+    ops.conv_gemm(x, dev(w), out[:, 4:4 + N], tile=20, **kw)
+    assert (out[:, 4:4 + N].cpu().double() - ref).abs().max() < 3e-5
+    assert (out[:, :4] == 7.0).all() and (out[:, 4 + N:] == 7.0).all()              # nothing written outside the column slice
+    out2 = torch.empty(M, N, device="cuda")
+    ops.conv_gemm(x, dev(w), out2, tile=3, **kw)
+    assert torch.equal(out[:, 4:4 + N], out2)
+
+
+@pytest.mark.parametrize("M,N,K,eps", [(65536, 512, 128, 1e-5), (777, 384, 128, 1e-6), (40000, 128, 64, 1e-5)])
+def test_gemm_layernorm_prologue(ops, M, N, K, eps):
+    """Linear(LayerNorm(x)) with the normalisation done on the A rows inside the row-streaming kernel (twins.py:787-790,
+    encoder.py:156-172) and gamma / beta folded into the weights, against fp64 torch."""
+    x = torch.randn(M, K, generator=g(1)) * 3 + 1
+    gam, bet = torch.rand(K, generator=g(2)) + 0.5, torch.randn(K, generator=g(3))
+    w, b = torch.randn(N, K, generator=g(4)) / K ** 0.5, torch.randn(N, generator=g(5))
+    ref = F.gelu(F.linear(F.layer_norm(x.double(), (K,), gam.double(), bet.double(), eps), w.double(), b.double()))
+    wf, bf = ops.fold_layernorm(dev(gam), dev(bet), dev(w), dev(b))
+    out = torch.empty(M, N, device="cuda")
+    ops.conv_gemm(dev(x), wf, out, bias=bf, act="gelu", ln_eps=eps)
+    assert (out.cpu().double() - ref).abs().max() < 3e-5
+    # the unfused chain (LayerNorm kernel + GEMM) agrees to rounding
+    y, out2 = torch.empty(M, K, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.layernorm(dev(x), dev(gam), dev(bet), y, eps)
+    ops.conv_gemm(y, dev(w), out2, bias=dev(b), act="gelu")
+    assert (out - out2).abs().max() < 2e-5
+    with pytest.raises(Exception):                                                 # a shape the kernel does not take is rejected, not mis-computed
+        ops.conv_gemm(torch.empty(64, 256, device="cuda"), torch.empty(32, 256, device="cuda"), torch.empty(64, 32, device="cuda"), ln_eps=eps)
+
+
+def test_gelu_epilogue_accuracy(ops):
+    """st_gelu (erfc polynomial, branch-free) against fp64 x * Phi(x) over [-9, 9]: as close as torch's own fp32 CPU GELU."""
+    n = 1 << 16
+    xs = torch.linspace(-9, 9, n)
+    a = torch.zeros(n, 32); a[:, 0] = xs
+    w = torch.zeros(32, 32); w[:, 0] = 1.0
+    out = torch.empty(n, 32, device="cuda")
+    ops.conv_gemm(dev(a), dev(w), out, act="gelu", tile=3)
+    ref = xs.double() * 0.5 * (1 + torch.erf(xs.double() / 2 ** 0.5))
+    err = (out[:, 0].cpu().double() - ref).abs()
+    cpu = (F.gelu(xs).double() - ref).abs()
+    assert err.max() < 6e-7, err.max()
+    assert err.max() <= 1.5 * cpu.max() + 1e-7 and err.mean() <= 1.5 * cpu.mean() + 1e-9
