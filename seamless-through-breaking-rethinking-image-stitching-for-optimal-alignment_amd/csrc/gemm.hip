@@ -1217,15 +1217,15 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     // tile choice: largest tile that still yields >= ~1.5 waves of workgroups over the 256 CUs
     auto nwg = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };
     int cfg = d.tile_cfg;
-    // the LDS-DMA pipelined kernel needs whole 32-channel K steps inside one tap; K < 256 (<= 8 steps) is all
-    // prologue / epilogue and gains nothing from it
+    // the LDS-DMA pipelined kernel needs whole 32-channel K steps inside one tap
     const bool dma_ok = aligned && d.Cin % 32 == 0;
     if (cfg == 0) {
         // measured on MI355X (tools/tile_sweep.py, tools/dma_sweep.py): the 64x64 tile wins for every short-K /
         // mid-size shape of this path (more resident workgroups); 128-wide tiles stay selectable through tile_cfg.
         const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M;
-        const bool stream128 = d.K == 128 && plain && d.N > 32 && nwg(64, 64) > 512;      // persistent walk hides the 4-step K loop
-        const bool dma = dma_ok && (d.K >= 256 || stream128);
+        // K >= 128 (four K steps): the DMA ring already beats the register-staged kernel by 25-35 % per launch
+        // (graph replay, tools/shortk_bench.py: 8192x256x160 14.4 -> 10.6 us, 8192x128x192 10.9 -> 7.6, 4096x128x128 7.8 -> 5.9)
+        const bool dma = dma_ok && d.K >= 128;
         if (d.N <= 32) cfg = dma ? 14 : 4;
         else cfg = dma ? 13 : 3;
     }

@@ -697,16 +697,9 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes visible to its own lanes
     if (!inb) return;
+    // one pass over the window's keys with a running maximum (scores are computed once; a new maximum rescales the
+    // running sum and accumulator -- rare after the first few keys)
     float mx = -INFINITY;
-    for (int j = 0; j < T; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < D; e += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(Ks + j * D + e);
-            s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
-        }
-        mx = fmaxf(mx, s * scale);
-    }
     float acc[D];
 #pragma unroll
     for (int e = 0; e < D; ++e) acc[e] = 0.f;
@@ -718,7 +711,15 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
             const float4 t = *reinterpret_cast<const float4*>(Ks + j * D + e);
             s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
         }
-        const float p = __expf(s * scale - mx);
+        s *= scale;
+        if (s > mx) {
+            const float r = __expf(mx - s);                       // exp(-inf) = 0 on the first key
+            sum *= r;
+#pragma unroll
+            for (int e = 0; e < D; ++e) acc[e] *= r;
+            mx = s;
+        }
+        const float p = __expf(s - mx);
         sum += p;
 #pragma unroll
         for (int e = 0; e < D; e += 4) {

@@ -162,9 +162,9 @@ class FlowFormer(ParamTree):
         f0 = torch.zeros((Q, 84), device=f0w.device)
         f0[:, :81] = f0w
         c1w = p[m + "update_block.encoder.convc1.weight"].reshape(256, 145)
-        c1 = torch.zeros((256, 148), device=c1w.device)
+        c1 = torch.zeros((256, 160), device=c1w.device)         # K padded to whole 32-channel steps (LDS-DMA kernel)
         c1[:, :81] = c1w[:, 64:]
-        c1[:, 84:] = c1w[:, :64]
+        c1[:, 84:148] = c1w[:, :64]
         ub = m + "update_block."
         pw, pb = p[m + "proj.weight"].reshape(256, 256).contiguous(), p[m + "proj.bias"].contiguous()
         ca = m + "decoder_layer.cross_attend"
@@ -458,8 +458,8 @@ class FlowFormer(ParamTree):
 
     def _update_state(self, R, B, N, dev):
         """work buffers of the refinement loop.  hxA = [h | motion(126)+flow(2) | motion_global], hxB = [r*h | same];
-        corr = [cost_forward 81 | 3 zero | cost_global 64]."""
-        return dict(hxA=_new(R, 384, dev), hxB=_new(R, 384, dev), corr=_new(R, 148, dev, zero=True), flow4=_new(R, 4, dev),
+        corr = [cost_forward 81 | 3 zero | cost_global 64 | 12 zero]."""
+        return dict(hxA=_new(R, 384, dev), hxB=_new(R, 384, dev), corr=_new(R, 160, dev, zero=True), flow4=_new(R, 4, dev),
                     cor1=_new(R, 256, dev), corflo=_new(R, 256, dev), flo1=_new(R, 128, dev),
                     vT=torch.empty((B, 128, N), device=dev), zbuf=_new(R, 128, dev), fh=_new(R, 256, dev))
 

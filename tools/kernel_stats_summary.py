@@ -1,0 +1,20 @@
+"""rocprofv3 --kernel-trace --stats summary -> ms per forward by kernel: python tools/kernel_stats_summary.py STATS.csv [FORWARDS]
+FORWARDS defaults to the call count of flow_warp_kernel (one per forward)."""
+import csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+def short(n):
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"\(.*", "", n)
+    return n[:78]
+fw = int(sys.argv[2]) if len(sys.argv) > 2 else next(int(r["Calls"]) for r in rows if "flow_warp_kernel" in r["Name"])
+tot = 0.0
+gemm = 0.0
+print(f"forwards: {fw}")
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+    ms = float(r["TotalDurationNs"]) / fw / 1e6
+    tot += ms
+    if any(k in r["Name"] for k in ("conv_gemm", "rowstream_gemm", "splitk_reduce", "narrow_conv", "skinny_gemm", "grouped_gemm")):
+        gemm += ms
+    if ms >= 0.004:
+        print(f"{ms:8.3f} ms  x{int(r['Calls']) / fw:7.1f}  avg {float(r['AverageNs']) / 1e3:8.1f} us  {short(r['Name'])}")
+print(f"total kernel time per forward {tot:.3f} ms; GEMM family {gemm:.3f} ms; other {tot - gemm:.3f} ms")
