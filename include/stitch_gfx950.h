@@ -59,6 +59,12 @@ typedef struct st_gemm_desc {
                               encoder.py:156-172; the caller folds gamma into W and beta into the bias).  Row-streaming
                               kernel only: plain matrix, K = 64 / 128, batch <= 1; anything else is rejected          */
     float a_ln_eps;
+    const float* a2;       /* optional second source of A with the SAME geometry and row stride: input channels c < a2_channels
+                              are read from a2, the others from a (SepConvGRU's q conv reads [r*h | x] as r*h from one
+                              buffer and x from the other, gru.py:50, without x being copied).  LDS-DMA kernel only
+                              (Cin % 32 == 0, a2_channels % 32 == 0, batch <= 1); anything else is rejected                 */
+    int32_t a2_channels;
+    int32_t reserved1;     /* must be 0 */
 } st_gemm_desc;
 
 /* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.
@@ -238,7 +244,7 @@ int st_gma_attention(const float* inp, int32_t ld_inp, const float* w_qk, float*
 int st_gma_aggregate(const float* attn, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma,
                      float* vT, float* out, int32_t ld_out, int32_t B, int32_t N, void* workspace,
                      int64_t workspace_floats, void* stream);
-/* SepConvGRU.forward (gru.py:44-59).  hxA rows [h(128) | x(ld-128)], hxB [r*h scratch | same x]; the constant
+/* SepConvGRU.forward (gru.py:44-59).  hxA rows [h(128) | x(ld-128)], hxB rows of the same stride [r*h scratch | unused]; the constant
  * `inp` channels arrive folded into tab1/tab2 [rows, ld_tab>=384] = conv_inp([z|r|q]) + bias; w_zr* [256,5*ld],
  * w_q* [128,5*ld] with K ordered (tap, channel); zbuf scratch [rows,128].  h is updated in place in hxA.   */
 int st_sepconv_gru(float* hxA, float* hxB, int32_t ld, float* zbuf, const float* tab1, const float* tab2,

@@ -569,6 +569,10 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const i32x4 rsrcA = make_rsrc(X, d.a_bytes), rsrcW = make_rsrc(Wt, d.w_bytes);
+    // optional second A source (same geometry): channels below a2_channels come from it -- a wave-uniform descriptor
+    // choice per issued piece, on the SALU
+    const i32x4 rsrcA2 = make_rsrc(d.a2 ? d.a2 : X, d.a_bytes);
+    const int a2c = (!PERSIST && d.a2) ? d.a2_channels : 0;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;   // LDS byte address
 
     // staging slots of this lane: wave w stages A rows [8*PA*w, 8*PA*(w+1)) and B rows [8*PB*w, 8*PB*(w+1)),
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
     };
     if (PERSIST) set_rows(); else set_tap();
     auto issue_a = [&](int stage, int i) {
-        lds_dma16(rsrcA, lds0 + (unsigned)(stage * STAGE_FLOATS + (wave * PA + i) * 256) * 4u, voffA[i], soffA);
+        lds_dma16(i_c0 < a2c ? rsrcA2 : rsrcA, lds0 + (unsigned)(stage * STAGE_FLOATS + (wave * PA + i) * 256) * 4u, voffA[i], soffA);
     };
     auto issue_b = [&](int stage, int i) {
         lds_dma16(rsrcW, lds0 + (unsigned)(stage * STAGE_FLOATS + BM * 32 + (wave * PB + i) * 256) * 4u, voffB[i], soffB);
@@ -1065,7 +1069,7 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
     const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M &&
                        d.Ho * d.Wo == d.M;
     const int slots = 512 / batch;
-    if (plain && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
+    if (plain && !d.a2 && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
         int G = slots / ntn;
         if (G > ntm) G = ntm;
         auto k = conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true>;
@@ -1119,7 +1123,8 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
-    if (d.reserved0 != 0) return ST_EINVAL;
+    if (d.reserved0 != 0 || d.reserved1 != 0) return ST_EINVAL;
+    if (d.a2 && (d.a2_channels <= 0 || d.a2_channels % 32 || d.a2_channels > d.Cin || d.batch > 1 || ((uintptr_t)d.a2 & 15))) return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // byte extents of one batch slice of A and W for the buffer descriptors (must stay below 2 GiB so the
     // out-of-range sentinel offset is always past num_records)
@@ -1165,6 +1170,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
                 st_gemm_desc c = *desc;
                 c.M = (int32_t)((d.M - m0) < chunk ? (d.M - m0) : chunk);
                 c.a = d.a + m0 / hw * img_rows * d.ldx;
+                if (d.a2) c.a2 = d.a2 + m0 / hw * img_rows * d.ldx;
                 c.c = d.c + m0 * d.ldc;
                 if (d.c2) c.c2 = d.c2 + m0 * d.ldc2;
                 if (d.aux1) c.aux1 = d.aux1 + m0 * d.ld_aux1;
@@ -1182,13 +1188,13 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
                          (d.ldw % 4 == 0) && (d.Cin % 4 == 0) &&
                          (d.batch_stride_a % 4 == 0) && (d.batch_stride_w % 4 == 0);
     const int batch = d.batch > 0 ? d.batch : 1;
-    if (d.M <= 8 && d.kh == 1 && d.kw == 1 && aligned && batch == 1 && d.epi == ST_EPI_STORE && !d.aux0 && d.H * d.W == d.M) {
+    if (d.M <= 8 && d.kh == 1 && d.kw == 1 && aligned && batch == 1 && d.epi == ST_EPI_STORE && !d.aux0 && d.H * d.W == d.M && !d.a2) {
         g_last_plan[0] = 0; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 0;
         hipLaunchKernelGGL(skinny_gemm_kernel<8>, dim3((d.N * 64 + 255) / 256), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;
     }
-    if (d.N <= 4 && aligned && batch == 1 && d.epi != ST_EPI_ZR && d.M >= 1024 && d.tile_cfg == 0 && d.split_k <= 1) {
+    if (d.N <= 4 && aligned && batch == 1 && d.epi != ST_EPI_ZR && d.M >= 1024 && d.tile_cfg == 0 && d.split_k <= 1 && !d.a2) {
         g_last_plan[0] = 1; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 0;
         hipLaunchKernelGGL(narrow_conv_kernel<4>, dim3((d.M + 3) / 4), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();
@@ -1200,7 +1206,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && (int64_t)d.H * d.W == d.M;
         const bool map_ok = (d.aux0_row_div <= 1 && (d.aux0_row_mod <= 0 || d.aux0_row_mod % 32 == 0)) ||
                             (d.aux0_row_div == 8 && d.aux0_row_mod <= 0) || !d.aux0;
-        const bool rs_ok = plain && aligned && batch == 1 && d.split_k <= 1 && (d.K == 64 || d.K == 128) &&
+        const bool rs_ok = plain && aligned && batch == 1 && !d.a2 && d.split_k <= 1 && (d.K == 64 || d.K == 128) &&
                            d.epi != ST_EPI_ZR && d.epi != ST_EPI_GRU && map_ok;
         // measured on MI355X, in the pipeline and stand-alone (tools/rowstream_bench.py): ahead of the LDS-DMA kernel for K = 64,
         // for M >= 262144 and for N >= 384; behind it by ~2 us per launch at M <= 65536, N = 128 (one block per wave: all
@@ -1230,6 +1236,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         else cfg = dma ? 13 : 3;
     }
     if (cfg > 10 && !dma_ok) return ST_EINVAL;
+    if (d.a2 && cfg <= 10) return ST_EINVAL;                   // the second A source exists in the LDS-DMA kernel only
     // split-K: a launch that cannot fill the 256 CUs (M = 4096-pixel maps x 64..256 channels) is cut
     // along K into slabs reduced by a second tiny kernel (deterministic order; no atomics).
     static const int bms[5] = {0, 128, 128, 64, 128}, bns[5] = {0, 128, 64, 64, 32};

@@ -39,6 +39,7 @@ struct Gemm {
     }
     Gemm& scale(const float* s) { d.scale_ptr = s; return *this; }
     Gemm& out2(float* c2, int32_t ld) { d.c2 = c2; d.ldc2 = ld; return *this; }
+    Gemm& a2(const float* p, int32_t channels) { d.a2 = p; d.a2_channels = channels; return *this; }
     Gemm& batched(int32_t n, int64_t sa, int64_t sw, int64_t sc) {
         d.batch = n; d.batch_stride_a = sa; d.batch_stride_w = sw; d.batch_stride_c = sc; return *this;
     }
@@ -133,8 +134,8 @@ int st_gma_aggregate(const float* attn, const float* mf, int32_t ld_mf, const fl
 }
 
 // SepConvGRU.forward (gru.py:44-59): horizontal (1x5) then vertical (5x1) gated update of h.
-//   hxA rows [B*H*W, ld] = [h(128) | x(ld-128)], hxB = [r*h scratch(128) | same x]  (x = motion features, already
-//   copied into both); the constant `inp` channels of the reference's hx are folded into the per-pass tables
+//   hxA rows [B*H*W, ld] = [h(128) | x(ld-128)], hxB rows [B*H*W, ld] = [r*h scratch(128) | unused]  (x = motion features;
+//   the q conv reads its first 128 input channels from hxB and the rest from hxA); the constant `inp` channels of the reference's hx are folded into the per-pass tables
 //   tab1/tab2 [B*H*W, 384] = conv_inp([z|r|q]) + bias.  Weights: w_zr* [256, 5*ld], w_q* [128, 5*ld], K ordered (tap, c).
 //   z = sigmoid(convz(hx)), r = sigmoid(convr(hx)), q = tanh(convq([r*h, x])), h = (1-z) h + z q.
 int st_sepconv_gru(float* hxA, float* hxB, int32_t ld, float* zbuf, const float* tab1, const float* tab2, int32_t ld_tab,
@@ -151,7 +152,7 @@ int st_sepconv_gru(float* hxA, float* hxB, int32_t ld, float* zbuf, const float*
         ST_TRY(Gemm(hxA, ld, wzr[p], 5 * ld, zbuf, 128, 0, 256, ld).conv(B, H, W, kh, kw, 1, 1, ph, pw)
                    .aux0(tabs[p], ld_tab).act(ST_ACT_SIGMOID).epi(ST_EPI_ZR, hxA, ld).out2(hxB, ld)
                    .work(workspace, workspace_floats).run(stream));
-        ST_TRY(Gemm(hxB, ld, wq[p], 5 * ld, hxA, ld, 0, 128, ld).conv(B, H, W, kh, kw, 1, 1, ph, pw)
+        ST_TRY(Gemm(hxA, ld, wq[p], 5 * ld, hxA, ld, 0, 128, ld).a2(hxB, 128).conv(B, H, W, kh, kw, 1, 1, ph, pw)
                    .aux0(tabs[p] + 256, ld_tab).act(ST_ACT_TANH).epi(ST_EPI_GRU, zbuf, 128, hxA, ld)
                    .work(workspace, workspace_floats).run(stream));
     }

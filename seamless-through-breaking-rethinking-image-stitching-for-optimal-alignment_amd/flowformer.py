@@ -457,7 +457,7 @@ class FlowFormer(ParamTree):
         return tabs
 
     def _update_state(self, R, B, N, dev):
-        """work buffers of the refinement loop.  hxA = [h | motion(126)+flow(2) | motion_global], hxB = [r*h | same];
+        """work buffers of the refinement loop.  hxA = [h | motion(126)+flow(2) | motion_global], hxB = [r*h | unused] (same stride);
         corr = [cost_forward 81 | 3 zero | cost_global 64 | 12 zero]."""
         return dict(hxA=_new(R, 384, dev), hxB=_new(R, 384, dev), corr=_new(R, 160, dev, zero=True), flow4=_new(R, 4, dev),
                     cor1=_new(R, 256, dev), corflo=_new(R, 256, dev), flo1=_new(R, 128, dev),
@@ -479,7 +479,6 @@ class FlowFormer(ParamTree):
         ops.conv_gemm(S["corflo"], D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu")
         # GMA aggregate: v^T = Wv . mf^T, out = mf + gamma * attn @ v
         ops.gma_aggregate(attn, hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], hxA[:, 256:], B, N)
-        ops.copy2d(hxA[:, 128:], hxB[:, 128:])
         # SepConvGRU: horizontal 1x5 then vertical 5x1
         ops.sepconv_gru(hxA, hxB, S["zbuf"], gru_tab["1"], gru_tab["2"], D["zr1"], D["q1"], D["zr2"], D["q2"], B, H1, W1)
         ops.conv_gemm(hxA[:, :128], D["fh1"][0], S["fh"], geom=g3, bias=D["fh1"][1], act="relu")

@@ -542,7 +542,8 @@ def test_sepconv_gru_operator(ops):
         return nhwc(torch.cat([F.conv2d(inp, wts[n + s][0][:, 128:256], wts[n + s][1], padding=pad) for n in "zrq"], 1))
 
     hxA, hxB = torch.zeros(R, 384, device="cuda"), torch.zeros(R, 384, device="cuda")
-    hxA[:, :128], hxA[:, 128:], hxB[:, 128:] = nhwc(h0), nhwc(x), nhwc(x)
+    hxA[:, :128], hxA[:, 128:] = nhwc(h0), nhwc(x)
+    hxB[:, 128:] = float("nan")             # never read: the q conv takes its x channels from hxA (second A source)
     zbuf = torch.empty(R, 128, device="cuda")
     ops.sepconv_gru(hxA, hxB, zbuf, table("1", (0, 2)), table("2", (2, 0)),
                     torch.cat([pack_hx(wts["z1"][0]), pack_hx(wts["r1"][0])]), pack_hx(wts["q1"][0]),
