@@ -153,7 +153,13 @@ int st_latent_pool(const float* scores, int32_t ld_s, const float* tokens, int32
 /* ---- FlowFormer decoder gathers --------------------------------------------------------------- */
 int st_coords_grid(float* out, int32_t B, int32_t H, int32_t W, void* stream);          /* decoder.py:22-29 */
 int st_flow_from_coords(const float* coords1, float* flow4, int32_t ld4, float* dst2, int32_t ld2, int32_t B,
-                        int32_t H, int32_t W, void* stream);                             /* decoder.py:321   */
+                        int32_t H, int32_t W, void* stream);
+/* BasicMotionEncoder flow branch, first layer, fused with the flow computation (gru.py:251, decoder.py:321):
+ * out [B*H*W, ldo] (first Co columns) = relu(Conv2d(2, Co, 7, padding=3)(coords1 - coords0)); w98 [49 taps][2][Co]
+ * (tap-major: w98[(ky*7+kx)*2 + c][co] = weight[co][c][ky][kx]); flow2 (optional) receives the flow itself in
+ * columns 0..1 of rows of stride ld2 (gru.py:254 cat([out, flow])).  Co % 4 == 0.                                 */
+int st_flow_encode(const float* coords1, const float* w98, const float* bias, float* out, int32_t ldo, float* flow2,
+                   int32_t ld2, int32_t B, int32_t H, int32_t W, int32_t Co, void* stream);                             /* decoder.py:321   */
 /* encode_flow_token + bilinear_sampler (decoder.py:242-260, core/utils/utils.py:62-76).              */
 int st_cost_lookup(const float* maps, const float* coords, float* out, int32_t ldo, int32_t Nq, int32_t H2,
                    int32_t W2, int32_t r, void* stream);

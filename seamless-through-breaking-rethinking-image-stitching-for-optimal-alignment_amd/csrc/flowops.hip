@@ -46,6 +46,98 @@ extern "C" int st_flow_from_coords(const float* coords1, float* flow4, int32_t l
     return ST_OK;
 }
 
+// BasicMotionEncoder's flow branch, first layer (gru.py:251 `flo = relu(convf1(flow))`, Conv2d(2, 128, 7, padding=3)) fused
+// with flow = coords1 - coords0 (decoder.py:321): a 2-channel 7x7 conv is 98 taps per output -- as an implicit GEMM
+// (K = 196 with the channels padded to 4) it ran on the register-staged fallback at 0.17 of the MFMA peak.  Here a lane
+// is an OUTPUT CHANNEL (w [49 taps][2][Co], tap-major, staged once per workgroup into LDS with 16-byte loads; a lane
+// reads the 14 weights of a kernel row into registers); a 512-thread workgroup takes an 8x4 pixel tile, builds the zero-padded 14x10 flow
+// patch in LDS from coords1, and each wave produces 64 channels for one row of 8 pixels: per kernel row 14 broadcast LDS
+// reads feed 112 FMAs on 8 independent accumulators; stores are whole 256-byte channel runs.  Also writes the flow
+// itself where the following layers want it (flow2 [.., ld2]: gru.py:254 cat([out, flow])).  (A first version with
+// lane = pixel and scalar-loaded weights was latency-bound on the scalar cache: 25 us.)
+__global__ __launch_bounds__(512) void flow_encode_kernel(const float* __restrict__ coords1, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                          float* __restrict__ flow2, int ld2, int H, int W, int Co) {
+    __shared__ float2 patch[10 * 14];
+    __shared__ __attribute__((aligned(16))) float wsm[98 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (W + 7) >> 3;
+    const int b = blockIdx.z, ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+    const size_t img = (size_t)b * H * W;
+    const int cbase = (int)blockIdx.y * 128;                          // this workgroup's 128 output channels
+    {
+        // weights of the channel block -> LDS [98][128] (Co % 4 == 0: rows are 16-byte aligned)
+        float4 v[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int f = u * 512 + tid, t = f >> 5, c4 = (f & 31) * 4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < 98 && cbase + c4 < Co) v[u] = *reinterpret_cast<const float4*>(w + (size_t)t * Co + cbase + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int f = u * 512 + tid;
+            if (f < 98 * 32) *reinterpret_cast<float4*>(wsm + f * 4) = v[u];
+        }
+    }
+    if (tid < 140) {
+        const int py = tid / 14, px = tid - py * 14;
+        const int y = ty * 4 + py - 3, x = tx * 8 + px - 3;
+        float2 f = make_float2(0.f, 0.f);
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const float2 cc = *reinterpret_cast<const float2*>(coords1 + (img + (size_t)y * W + x) * 2);
+            f = make_float2(cc.x - (float)x, cc.y - (float)y);
+        }
+        patch[tid] = f;
+    }
+    __syncthreads();
+    const int row = wave >> 1;                                       // pixel row of the tile (wave-uniform)
+    const int y = ty * 4 + row;
+    if (y >= H) return;
+    const int cl = (wave & 1) * 64 + lane, c = cbase + cl;           // this lane's output channel
+    const bool cok = c < Co;
+    const float bv = cok ? bias[c] : 0.f;
+    float acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = bv;
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+        float2 f[14];
+        float wr[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            f[i] = patch[(row + ky) * 14 + i];                      // same address in every lane: broadcast
+            wr[i] = wsm[(ky * 14 + i) * 128 + cl];                  // the lane's weights of this kernel row: (kx, component)
+        }
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                acc[p] = fmaf(f[p + kx].x, wr[kx * 2], acc[p]);
+                acc[p] = fmaf(f[p + kx].y, wr[kx * 2 + 1], acc[p]);
+            }
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int x = tx * 8 + p;
+        if (x < W && cok) out[(img + (size_t)y * W + x) * ldo + c] = fmaxf(acc[p], 0.f);
+    }
+    if (flow2 && blockIdx.y == 0 && (wave & 1) == 0 && lane < 8 && tx * 8 + lane < W) {
+        const float2 f = patch[(row + 3) * 14 + lane + 3];
+        const size_t r = img + (size_t)y * W + tx * 8 + lane;
+        flow2[r * ld2] = f.x; flow2[r * ld2 + 1] = f.y;
+    }
+}
+
+extern "C" int st_flow_encode(const float* coords1, const float* w98, const float* bias, float* out, int32_t ldo, float* flow2,
+                              int32_t ld2, int32_t B, int32_t H, int32_t W, int32_t Co, void* stream) {
+    if (!coords1 || !w98 || !bias || !out || B <= 0 || H <= 0 || W <= 0 || Co <= 0 || (Co & 3) || ((uintptr_t)w98 & 15)) return ST_EINVAL;
+    dim3 grid(((H + 3) / 4) * ((W + 7) / 8), (Co + 127) / 128, B);
+    hipLaunchKernelGGL(flow_encode_kernel, grid, dim3(512), 0, (hipStream_t)stream, coords1, w98, bias, out, ldo, flow2, ld2, H, W, Co);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 // 9x9 bilinear cost lookup: encode_flow_token + bilinear_sampler (decoder.py:242-260,
 // core/utils/utils.py:62-76).  Every query pixel n samples ITS OWN cost map (row n of the
 // all-pairs volume, [H2, W2]) at coords1[n] + (i-r, j-r): the first grid axis (i) goes to x

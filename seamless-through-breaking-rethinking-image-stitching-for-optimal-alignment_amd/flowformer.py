@@ -173,7 +173,8 @@ class FlowFormer(ParamTree):
             proj_net=(pw[:128].contiguous(), pb[:128].contiguous()), proj_inp=(pw[128:].contiguous(), pb[128:].contiguous()),
             ca=attn_layer(ca, False), qk=pack_conv(p[m + "att.to_qk.weight"]),
             convc1=(c1.contiguous(), p[ub + "encoder.convc1.bias"].contiguous()), convc2=conv(ub + "encoder.convc2"),
-            convf1=conv(ub + "encoder.convf1", 4), convf2=conv(ub + "encoder.convf2"), conv=conv(ub + "encoder.conv"),
+            convf1=(p[ub + "encoder.convf1.weight"].permute(2, 3, 1, 0).reshape(98, 128).contiguous(),      # [tap][c][co]
+                    p[ub + "encoder.convf1.bias"].contiguous()), convf2=conv(ub + "encoder.convf2"), conv=conv(ub + "encoder.conv"),
             to_v=pack_conv(p[ub + "aggregator.to_v.weight"]), gamma=p[ub + "aggregator.gamma"].contiguous(),
             fh1=conv(ub + "flow_head.conv1"), fh2=conv(ub + "flow_head.conv2"), m0=conv(ub + "mask.0"))
         cad = dec["ca"]
@@ -459,7 +460,7 @@ class FlowFormer(ParamTree):
     def _update_state(self, R, B, N, dev):
         """work buffers of the refinement loop.  hxA = [h | motion(126)+flow(2) | motion_global], hxB = [r*h | unused] (same stride);
         corr = [cost_forward 81 | 3 zero | cost_global 64 | 12 zero]."""
-        return dict(hxA=_new(R, 384, dev), hxB=_new(R, 384, dev), corr=_new(R, 160, dev, zero=True), flow4=_new(R, 4, dev),
+        return dict(hxA=_new(R, 384, dev), hxB=_new(R, 384, dev), corr=_new(R, 160, dev, zero=True),
                     cor1=_new(R, 256, dev), corflo=_new(R, 256, dev), flo1=_new(R, 128, dev),
                     vT=torch.empty((B, 128, N), device=dev), zbuf=_new(R, 128, dev), fh=_new(R, 256, dev))
 
@@ -469,12 +470,11 @@ class FlowFormer(ParamTree):
         (decoder.py:329).  Reads S['corr'] (cost_forward | cost_global), updates S['hxA'][:, :128] (net) and coords1."""
         D = self._pk["dec"]
         N = H1 * W1
-        hxA, hxB, corr, flow4 = S["hxA"], S["hxB"], S["corr"], S["flow4"]
+        hxA, hxB, corr = S["hxA"], S["hxB"], S["corr"]
         g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
-        ops.flow_from_coords(coords1, flow4, hxA[:, 254:256], B, H1, W1)                          # :321, gru.py:254
         ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu")
         ops.conv_gemm(S["cor1"], D["convc2"][0], S["corflo"][:, :192], geom=g3, bias=D["convc2"][1], act="relu")
-        ops.conv_gemm(flow4, D["convf1"][0], S["flo1"], geom=(B, H1, W1, 7, 7, 1, 1, 3, 3), bias=D["convf1"][1], act="relu")
+        ops.flow_encode(coords1, D["convf1"][0], D["convf1"][1], S["flo1"], hxA[:, 254:256], B, H1, W1)      # :321, gru.py:251,254
         ops.conv_gemm(S["flo1"], D["convf2"][0], S["corflo"][:, 192:], geom=g3, bias=D["convf2"][1], act="relu")
         ops.conv_gemm(S["corflo"], D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu")
         # GMA aggregate: v^T = Wv . mf^T, out = mf + gamma * attn @ v

@@ -233,6 +233,13 @@ def flow_from_coords(coords1, flow4, dst2, B, H, W):
                                   _ld(dst2) if dst2 is not None else 0, B, H, W, _stream()), "st_flow_from_coords")
 
 
+def flow_encode(coords1, w98, bias, out, flow2, B, H, W):
+    """out[:, :Co] = relu(conv7x7(coords1 - grid)); flow2[:, :2] = the flow (gru.py:251,254, decoder.py:321)."""
+    check(lib.st_flow_encode(_pc(coords1), _pc(w98), _pc(bias), _p(out), _ld(out), _p(flow2), _ld(flow2) if flow2 is not None else 0,
+                             B, H, W, w98.shape[1], _stream()), "st_flow_encode")
+    return out
+
+
 def cost_lookup(maps, coords, out, Nq, H2, W2, r=4):
     check(lib.st_cost_lookup(_p(maps), _p(coords), _p(out), _ld(out), Nq, H2, W2, r, _stream()), "st_cost_lookup")
     return out

@@ -716,3 +716,20 @@ def test_gelu_epilogue_accuracy(ops):
     cpu = (F.gelu(xs).double() - ref).abs()
     assert err.max() < 6e-7, err.max()
     assert err.max() <= 1.5 * cpu.max() + 1e-7 and err.mean() <= 1.5 * cpu.mean() + 1e-9
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 13, 22)])
+def test_flow_encode(ops, B, H, W):
+    """flow = coords1 - coords0 and relu(convf1(flow)) (Conv2d(2, 128, 7, padding=3); gru.py:251, decoder.py:321) in one kernel,
+    against fp64 torch; ragged tiles; the flow lands in two columns of a wider buffer."""
+    flow = torch.randn(B, 2, H, W, generator=g(1)) * 4
+    wt, b = torch.randn(128, 2, 7, 7, generator=g(2)) / 98 ** 0.5, torch.randn(128, generator=g(3))
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    coords1 = (flow + torch.stack([xs, ys])[None]).permute(0, 2, 3, 1).reshape(-1, 2)
+    ref = F.relu(F.conv2d(flow.double(), wt.double(), b.double(), padding=3)).permute(0, 2, 3, 1).reshape(-1, 128)
+    out = torch.full((B * H * W, 136), 7.0, device="cuda")
+    wide = torch.full((B * H * W, 8), 7.0, device="cuda")
+    ops.flow_encode(dev(coords1), dev(wt.permute(2, 3, 1, 0).reshape(98, 128)), dev(b), out[:, 4:132], wide[:, 5:7], B, H, W)
+    assert (out[:, 4:132].cpu().double() - ref).abs().max() < 2e-5
+    assert (out[:, :4] == 7.0).all() and (out[:, 132:] == 7.0).all()
+    assert (wide[:, 5:7].cpu() - flow.permute(0, 2, 3, 1).reshape(-1, 2)).abs().max() < 1e-5 and (wide[:, :5] == 7.0).all() and (wide[:, 7] == 7.0).all()
