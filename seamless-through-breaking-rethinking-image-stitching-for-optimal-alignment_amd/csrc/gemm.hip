@@ -1035,6 +1035,85 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const st_gemm_desc d) 
     }
 }
 
+// The flow head's second conv (gru.py:5-13: Conv2d(256, 2, 3, padding=1)) and its like: 3x3, stride 1, pad 1, Cin = 256,
+// N <= 2.  A lane owns 4 input channels and keeps its 9 x N weight quads in registers; a wave produces 8 consecutive
+// output pixels of one image row: per kernel row it loads the 10 input pixels it needs once (whole 1-KiB channel
+// rows), 9 x 8 x N dot-4 updates, then ONE transposing butterfly reduces the 8 x N partial sums across the wave
+// (17 shuffles instead of 6 per value).  Input pixels are fetched 30 times per wave instead of 72, weights once
+// instead of once per pixel (narrow_conv_kernel: 17 us at M = 8192; this: ~5 us).
+template <int NOUT>
+__global__ __launch_bounds__(256) void narrow_conv3x3_kernel(const st_gemm_desc d) {
+    constexpr int NV = 8 * NOUT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int segs = (d.W + 7) >> 3;
+    const int wid = blockIdx.x * 4 + wave;
+    const int nimg = d.M / (d.H * d.W);
+    if (wid >= nimg * d.H * segs) return;
+    const int b = wid / (d.H * segs), r = wid - b * d.H * segs;
+    const int y = r / segs, x0 = (r - y * segs) * 8;
+    float4 wv[NOUT][9];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            wv[n][t] = n < d.N ? *reinterpret_cast<const float4*>(d.w + (size_t)n * d.ldw + t * 256 + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+        if (iy < 0 || iy >= d.H) continue;                           // wave-uniform
+        float4 in[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int ix = x0 - 1 + i;
+            in[i] = (ix >= 0 && ix < d.W) ? *reinterpret_cast<const float4*>(d.a + ((size_t)(b * d.H + iy) * d.W + ix) * d.ldx + 4 * lane)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int n = 0; n < NOUT; ++n) {
+                    const float4 xv = in[p + kx], w4 = wv[n][ky * 3 + kx];
+                    float a = acc[p * NOUT + n];
+                    a = fmaf(xv.x, w4.x, a); a = fmaf(xv.y, w4.y, a); a = fmaf(xv.z, w4.z, a); a = fmaf(xv.w, w4.w, a);
+                    acc[p * NOUT + n] = a;
+                }
+    }
+    // transposing butterfly: each step halves the number of values a lane carries; after log2(NV) steps lane l holds the
+    // 64 / NV-lane partial sum of value v(l), v's bits taken from the lane bits used so far (high bits first)
+    int cnt = NV / 2;
+#pragma unroll
+    for (int s = 32; cnt >= 1; s >>= 1, cnt >>= 1) {
+        const bool hi = lane & s;
+#pragma unroll
+        for (int i = 0; i < NV / 2; ++i)
+            if (i < cnt) {
+                const float send = hi ? acc[i] : acc[i + cnt], keep = hi ? acc[i + cnt] : acc[i];
+                acc[i] = keep + __shfl_xor(send, s, 64);
+            }
+    }
+    constexpr int STEPS = NOUT == 1 ? 3 : NOUT == 2 ? 4 : 5;          // log2(NV)
+    float v = acc[0];
+#pragma unroll
+    for (int s = 32 >> STEPS; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    if ((lane & ((64 >> STEPS) - 1)) == 0) {
+        int idx = 0, c = NV / 2;
+#pragma unroll
+        for (int s = 32; c >= 1; s >>= 1, c >>= 1) idx += (lane & s) ? c : 0;
+        const int p = idx / NOUT, n = idx - p * NOUT;
+        const int x = x0 + p;
+        if (x < d.W && n < d.N) {
+            const int m = (b * d.H + y) * d.W + x;
+            const float sc = d.scale_ptr ? *d.scale_ptr : 1.0f;
+            d.c[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, v, sc);
+        }
+    }
+}
+
 static thread_local int32_t g_last_plan[4] = {-1, 0, 0, 0};
 
 template <int WARPS_M, int WARPS_N, int TM, int TN>
@@ -1196,6 +1275,13 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     }
     if (d.N <= 4 && aligned && batch == 1 && d.epi != ST_EPI_ZR && d.M >= 1024 && d.tile_cfg == 0 && d.split_k <= 1 && !d.a2) {
         g_last_plan[0] = 1; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 0;
+        if (d.N <= 2 && d.Cin == 256 && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 && d.dh <= 1 && d.dw <= 1 &&
+            d.Ho == d.H && d.Wo == d.W) {
+            const int waves = (d.M / (d.H * d.W)) * d.H * ((d.W + 7) / 8);
+            hipLaunchKernelGGL(narrow_conv3x3_kernel<2>, dim3((waves + 3) / 4), dim3(256), 0, s, d);
+            ST_CHECK_LAUNCH();
+            return ST_OK;
+        }
         hipLaunchKernelGGL(narrow_conv_kernel<4>, dim3((d.M + 3) / 4), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;

@@ -620,9 +620,11 @@ def test_gemm_dma_persistent_walk(ops, M, N, K):
     assert torch.equal(out, out2)            # same k order as the register-staged kernel: bit-identical
 
 
-def test_narrow_conv(ops):
-    """N <= 4 (flow head conv2, gru.py:5-13): one wave per output pixel, coords += delta epilogue."""
-    B, H, W, C = 2, 32, 32, 256
+@pytest.mark.parametrize("H,W,C", [(32, 32, 256), (9, 13, 256), (16, 16, 128)])
+def test_narrow_conv(ops, H, W, C):
+    """N <= 4 (flow head conv2, gru.py:5-13), coords += delta epilogue: the 3x3 / 256-channel kernel (8 pixels per wave, weights in
+    registers), ragged rows, and the generic one-wave-per-pixel kernel (C = 128)."""
+    B = 2
     x = torch.randn(B, C, H, W, generator=g(1))
     w, b = torch.randn(2, C, 3, 3, generator=g(2)) / (9 * C) ** 0.5, torch.randn(2, generator=g(3))
     coords = torch.randn(B * H * W, 2, generator=g(4))
