@@ -110,8 +110,8 @@ int st_maxpool_nhwc(const float* x, float* out, int32_t B, int32_t H, int32_t W,
 int st_dwconv3x3_residual(const float* x, const float* w, const float* bias, float* out, int32_t B,
                           int32_t H, int32_t W, int32_t C, void* stream);
 /* LinearPositionEmbeddingSine (attention.py:156-161); coords [rows, ldc]=(x,y) or implicit grid
- * (r = row % period; r -> (r % Wg, r / Wg), optionally modulo ws), value*cscale + coff; write or
- * accumulate.                                                                                      */
+ * (r = row % period; r -> (r % Wg, r / Wg), optionally modulo ws), value*cscale + coff; accumulate: 0 = write,
+ * 1 = add to what is there, n > 1 = write columns < n and add to columns >= n.                      */
 int st_sine_pe(float* out, int32_t ld, int32_t rows, int32_t dim, const float* coords, int32_t ldc,
                int32_t Wg, int32_t ws, int32_t period, float cscale, float coff, int32_t accumulate,
                void* stream);

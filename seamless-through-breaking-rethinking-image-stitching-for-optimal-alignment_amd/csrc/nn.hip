@@ -245,8 +245,15 @@ __global__ void sine_pe_kernel(float* __restrict__ out, int ld, int rows, int di
     const float ax = ((3.14f * x) * fb) * 0.005f, ay = ((3.14f * y) * fb) * 0.005f;
     float* o = out + (size_t)row * ld;
     const float v0 = sinf(ax), v1 = cosf(ax), v2 = sinf(ay), v3 = cosf(ay);
-    if (accumulate) { o[f] += v0; o[q + f] += v1; o[2 * q + f] += v2; o[3 * q + f] += v3; }
-    else { o[f] = v0; o[q + f] = v1; o[2 * q + f] = v2; o[3 * q + f] = v3; }
+    // accumulate: 0 = write, 1 = add, n > 1 = write the columns below n and add to the others (a buffer whose first
+    // n columns carry no other term needs no zero fill)
+    const float val[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * q + f;
+        if (accumulate == 1 || (accumulate > 1 && c >= accumulate)) o[c] += val[i];
+        else o[c] = val[i];
+    }
 }
 
 extern "C" int st_sine_pe(float* out, int32_t ld, int32_t rows, int32_t dim, const float* coords, int32_t ldc, int32_t Wg,

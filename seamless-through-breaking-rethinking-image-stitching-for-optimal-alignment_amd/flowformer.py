@@ -150,6 +150,12 @@ class FlowFormer(ParamTree):
                 gskb=p[gb + "attn.sr_key.bias"].contiguous(), gsv=conv(gb + "attn.sr_value")))
             vert[-1]["lqkv"] = torch.cat([vert[-1]["lq"][0][:, :128], vert[-1]["lk"][0][:, :128], vert[-1]["lv"][0]], 0).contiguous()
             vert[-1]["gskv"] = torch.cat([vert[-1]["gskx"], vert[-1]["gsv"][0]], 0).contiguous()   # sr_key (x part) | sr_value
+            Vd = vert[-1]
+            # per-pixel pre-activation tables in ONE product each: [q | k | v-bias] of the local block (the v columns have zero
+            # weights: they carry v's bias), [sr_key over the context channels | sr_value's bias] of the global block
+            z128 = torch.zeros_like(Vd["lq"][0])
+            Vd["ltab"] = (torch.cat([Vd["lq"][0], Vd["lk"][0], z128], 0).contiguous(), torch.cat([Vd["lq"][1], Vd["lk"][1], Vd["lv"][1]]).contiguous())
+            Vd["gtab"] = (torch.cat([Vd["gskc"], torch.zeros_like(Vd["gskc"])], 0).contiguous(), torch.cat([Vd["gskb"], Vd["gsv"][1]]).contiguous())
             vert[-1]["lqkv_ln"] = ops.fold_layernorm(*vert[-1]["ln1"], vert[-1]["lqkv"])
             vert[-1]["lfc1_ln"] = ops.fold_layernorm(*vert[-1]["ln2"], *vert[-1]["lfc1"])
             vert[-1]["gfc1_ln"] = ops.fold_layernorm(*vert[-1]["gn2"], *vert[-1]["gfc1"])
@@ -357,14 +363,13 @@ class FlowFormer(ParamTree):
         y = _new(R, C, dev)
         if not FUSE_LN:
             ops.layernorm(x, V["ln1"][0], V["ln1"][1], y, 1e-5)
-        z = _new(B * N, Cq, dev, zero=True)
+        z = _new(B * N, Cq, dev)                                             # [0 + code | context projection + code]
         ops.conv_gemm(ctx, V["lctx"][0], z[:, C:], bias=V["lctx"][1])
-        ops.sine_pe(z, Cq, Wg=W1, ws=7, period=N, accumulate=True)          # window-local code (twins.py:285-288)
+        ops.sine_pe(z, Cq, Wg=W1, ws=7, period=N, accumulate=C)             # window-local code (twins.py:285-288)
         # q | k | v of every latent row in ONE N = 384 product: the context / position part of q and k is a per-pixel
         # table (row = m / nl), v's bias rides in the same table
-        T = V["lv"][1].repeat(3).expand(B * N, 3 * C).contiguous()
-        ops.conv_gemm(z, V["lq"][0], T[:, :C], bias=V["lq"][1])
-        ops.conv_gemm(z, V["lk"][0], T[:, C:2 * C], bias=V["lk"][1])
+        T = _new(B * N, 3 * C, dev)
+        ops.conv_gemm(z, V["ltab"][0], T, bias=V["ltab"][1])
         qkv = _new(R, 3 * C, dev)
         if FUSE_LN:
             ops.conv_gemm(x, V["lqkv_ln"][0], qkv, bias=V["lqkv_ln"][1], aux0=T, row_div=nl, ln_eps=1e-5)
@@ -390,15 +395,15 @@ class FlowFormer(ParamTree):
         x2 = self._mlp(x1, V["ln2"], V["lfc1"], V["lfc2"], 1e-5, fc1_ln=V["lfc1_ln"])
         # ---------------- global block
         ops.layernorm(x2, V["gn1"][0], V["gn1"][1], y, 1e-5)
-        z = _new(B * N, Cq, dev, zero=True)
+        z = _new(B * N, Cq, dev)
         ops.conv_gemm(ctx, V["gctx"][0], z[:, C:], bias=V["gctx"][1])
         Hk, Wk = H1 // 4, W1 // 4
         Nk = Hk * Wk
         # pre-activation table of the fused [sr_key | sr_value] conv: key half = sr_key over the context channels + bias,
         # value half = sr_value's bias
-        Tkv = V["gsv"][1].repeat(2).expand(B * Nk, 2 * C).contiguous()
-        ops.conv_gemm(z[:, C:], V["gskc"], Tkv[:, :C], geom=(B, H1, W1, 4, 4, 4, 4, 0, 0), bias=V["gskb"])
-        ops.sine_pe(z, Cq, Wg=W1, period=N, accumulate=True)                 # full-grid code on q (twins.py:358-361)
+        Tkv = _new(B * Nk, 2 * C, dev)
+        ops.conv_gemm(z[:, C:], V["gtab"][0], Tkv, geom=(B, H1, W1, 4, 4, 4, 4, 0, 0), bias=V["gtab"][1])
+        ops.sine_pe(z, Cq, Wg=W1, period=N, accumulate=C)                    # full-grid code on q (twins.py:358-361)
         Tq, q = _new(B * N, C, dev), _new(R, C, dev)
         ops.conv_gemm(z, V["gq"][0], Tq, bias=V["gq"][1])
         ops.conv_gemm(y, V["gq"][0][:, :C], q, aux0=Tq, row_div=nl)

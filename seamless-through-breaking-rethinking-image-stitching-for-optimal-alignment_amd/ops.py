@@ -175,7 +175,7 @@ def dwconv3x3_residual(x, w9c, bias, out, B, H, W, Cc):
 
 def sine_pe(out, dim, *, coords=None, Wg=0, ws=0, period=0, cscale=1.0, coff=0.0, accumulate=False):
     check(lib.st_sine_pe(_p(out), _ld(out), out.shape[0], dim, _p(coords), _ld(coords) if coords is not None else 0,
-                         Wg, ws, period, cscale, coff, int(accumulate), _stream()), "st_sine_pe")
+                         Wg, ws, period, cscale, coff, int(accumulate), _stream()), "st_sine_pe")       # accumulate: False / True / first added column
     return out
 
 
