@@ -55,6 +55,22 @@ def forward_test_eval(sd, img1, img2, iters=12, stages=None, motion=None):
                 flow_predictions=[flow_ij], H=H, origin_occlusion_mask=occ.squeeze(1))
 
 
+def blend_canvas(homo1, homo2, final):
+    """Mask algebra + uint8 blend of test_out_forward (core/flowHomoAdpater.py:339-360): homo1 / homo2 = [image | mask] of the
+    reference / warped view on the canvas, final = flow-warped view already multiplied by the occlusion mask.
+    Returns (output1, output2, mask1, mask2, blend_image uint8)."""
+    o1, m1 = homo1[:, 0:3], homo1[:, 3:6]
+    o2, m2 = final[:, 0:3], final[:, 3:6]
+    nov = 1 - m1
+    o2 = homo2[:, 0:3] * (1 - m2) * nov + o2 * m2                                    # :345
+    m2 = homo2[:, 3:6] * (1 - m2) * nov + m2 * m2                                    # :346
+    blend = ((o1 * m1 + o2 * m2) / (m1 + m2)).clip(0, 255)                           # :355-356
+    blend = torch.nan_to_num(blend, nan=0.0).to(torch.uint8)                         # CPU NaN -> 0
+    m1o = m1.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1)
+    m2o = m2.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1)
+    return o1, o2, m1o, m2o, blend
+
+
 def forward_test_out(sd, img1, img2, iters=12):
     """type='test_out' (flowHomoAdpater.py:197-377); batch must be 1 (shared canvas)."""
     B, _, ih, iw = img1.shape
@@ -96,15 +112,7 @@ def forward_test_out(sd, img1, img2, iters=12):
     origin_occ = occ.clone()
     occ = geom.morph_open19(geom.homo_transformer(occ, I_mat, (oh, ow)))             # :335-336
     final = final * occ
-    o1, m1 = homo1[:, 0:3], homo1[:, 3:6]
-    o2, m2 = final[:, 0:3], final[:, 3:6]
-    nov = 1 - m1
-    o2 = homo2[:, 0:3] * (1 - m2) * nov + o2 * m2                                    # :345
-    m2 = homo2[:, 3:6] * (1 - m2) * nov + m2 * m2                                    # :346
-    blend = ((o1 * m1 + o2 * m2) / (m1 + m2)).clip(0, 255)                           # :355-356
-    blend = torch.nan_to_num(blend, nan=0.0).to(torch.uint8)                         # CPU NaN -> 0
-    m1o = m1.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1)
-    m2o = m2.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1)
+    o1, o2, m1o, m2o, blend = blend_canvas(homo1, homo2, final)
     return dict(H_warp=homo2[:, 0:3], final_warp=final[:, 0:3], output1=o1, output2=o2, mask1=m1o, mask2=m2o,
                 blend_image=blend, residual_flow=residual, width_min=int(wmin), height_min=int(hmin),
                 out_height=oh, out_width=ow, H=Hc, warp_input2_mask=m512, warp_input2_tensor_512=warp2_512,

@@ -269,3 +269,39 @@ void orc_dlt4(const float *src, const float *dst, float *H) {
     orc_matmul_small(Ainv, b, H, 8, 8, 1);
     H[8] = 1.0f;
 }
+
+
+/* fp64 inverse of a row-major n x n matrix by Gauss-Jordan elimination with partial pivoting: the TPS system of
+ * core/udis_utils/torch_tps_transform.py:173 (`torch.inverse(W)` on an (N+3)^2 fp64 matrix).  The reference's result is
+ * LAPACK dgetrf + dgetri; in fp64 the two differ by ~1e-13 relative, which the cast of T to fp32 (:185) absorbs except for
+ * last-bit ties -- the test bound on T is 1e-6 relative.  Plain C on purpose: MKL's threaded batched dgetrf returned
+ * inconsistent pivots on a GPU box ("Intel oneMKL ERROR: Parameter 6 was incorrect on entry to DLASWP", round 2), which
+ * made the checker itself flaky.  work: n * 2n doubles.  Returns 0, or 1 if a pivot is exactly zero.               */
+int orc_inv_f64(const double *A, double *out, int n, double *work) {
+    const int ld = 2 * n;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) { work[i * ld + j] = A[i * n + j]; work[i * ld + n + j] = (i == j) ? 1.0 : 0.0; }
+    }
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        double best = fabs(work[c * ld + c]);
+        for (int r = c + 1; r < n; ++r) {
+            const double v = fabs(work[r * ld + c]);
+            if (v > best) { best = v; p = r; }
+        }
+        if (best == 0.0) return 1;
+        if (p != c)
+            for (int j = 0; j < ld; ++j) { const double t = work[c * ld + j]; work[c * ld + j] = work[p * ld + j]; work[p * ld + j] = t; }
+        const double inv = 1.0 / work[c * ld + c];
+        for (int j = 0; j < ld; ++j) work[c * ld + j] *= inv;
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = work[r * ld + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < ld; ++j) work[r * ld + j] -= f * work[c * ld + j];
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) out[i * n + j] = work[i * ld + n + j];
+    return 0;
+}

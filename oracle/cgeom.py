@@ -83,3 +83,17 @@ def dlt4(src, dst):
     for s, d, h in zip(src, dst, H):
         lib().orc_dlt4(_p(s), _p(d), _p(h))
     return H.reshape(-1, 3, 3)
+
+
+def inverse_f64(A):
+    """fp64 inverse of [..., n, n] by Gauss-Jordan with partial pivoting in plain C (no LAPACK: deterministic on every host)."""
+    A = np.ascontiguousarray(A, np.float64)
+    n = A.shape[-1]
+    out = np.empty_like(A)
+    work = np.empty(2 * n * n, np.float64)
+    fn = lib().orc_inv_f64
+    fn.restype = C.c_int
+    for a, o in zip(A.reshape(-1, n, n), out.reshape(-1, n, n)):
+        if fn(_p(a, C.c_double), _p(o, C.c_double), C.c_int(n), _p(work, C.c_double)):
+            raise np.linalg.LinAlgError("singular matrix")
+    return out

@@ -140,7 +140,10 @@ def tps_transformer(U, source, target, out_hw):
     W1 = torch.cat([torch.zeros(B, 3, 3), p.permute(0, 2, 1)], 2)
     Wm = torch.cat([W0, W1], 1).double()
     tp = torch.cat([target, torch.zeros(B, 3, 2)], 1).double()
-    T = torch.matmul(torch.inverse(Wm), tp).permute(0, 2, 1).float()      # [B,2,N+3]
+    # torch.inverse (fp64) restated in plain C (cgeom.inverse_f64): MKL's threaded batched dgetrf proved non-deterministic on a
+    # GPU box in round 2 (DLASWP parameter errors -> garbage pivots), and a checker must not be flaky
+    Winv = torch.from_numpy(cgeom.inverse_f64(Wm.numpy()))
+    T = torch.matmul(Winv, tp).permute(0, 2, 1).float()                   # [B,2,N+3]
     # _meshgrid :96-125
     xt = torch.from_numpy(cgeom.linspace(-1.0, 1.0, ow))[None, :].expand(oh, -1).reshape(1, 1, -1)
     yt = torch.from_numpy(cgeom.linspace(-1.0, 1.0, oh))[:, None].expand(-1, ow).reshape(1, 1, -1)
@@ -152,7 +155,7 @@ def tps_transformer(U, source, target, out_hw):
     return tps_interpolate(U, Tg[:, 0], Tg[:, 1], (oh, ow)), T
 
 
-def tps_indices(source, T, in_hw, out_hw):
+def tps_indices(source, T, in_hw, out_hw, return_frac=False):
     """Sample indices (x0, x1, y0, y1) [B,oh,ow,4] int32 of the TPS transformer for control points `source` and solved
     coefficients T [B,2,N+3] (torch_tps_transform.py:96-147 grid + T@grid, :29-41 index arithmetic)."""
     B, N, _ = source.shape
@@ -175,7 +178,12 @@ def tps_indices(source, T, in_hw, out_hw):
         return np.where(bad, -2147483648, np.where(bad, 0, fl).astype(np.int64))
     x0, y0 = toint(x), toint(y)
     out = np.stack([np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1), np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)], -1)
-    return torch.from_numpy(out.astype(np.int32).reshape(B, oh, ow, 4))
+    idx = torch.from_numpy(out.astype(np.int32).reshape(B, oh, ow, 4))
+    if not return_frac:
+        return idx
+    # distance of each sample coordinate to the nearest integer (where floor() is decided by the last bit)
+    fx, fy = np.abs(x - np.round(x)), np.abs(y - np.round(y))
+    return idx, torch.from_numpy(np.minimum(fx, fy).reshape(B, oh, ow))
 
 
 def tps_interpolate(U, xs, ys, out_hw):

@@ -78,7 +78,7 @@ def test_prepack_layouts(seeded_sd):
     pk = m.flow_backbone.pack()
     c1 = pk["dec"]["convc1"][0]
     w = seeded_sd["flow_backbone.memory_decoder.update_block.encoder.convc1.weight"].reshape(256, 145)
-    assert torch.equal(c1[:, :81], w[:, 64:]) and torch.equal(c1[:, 84:], w[:, :64]) and (c1[:, 81:84] == 0).all()
+    assert torch.equal(c1[:, :81], w[:, 64:]) and torch.equal(c1[:, 84:148], w[:, :64]) and (c1[:, 81:84] == 0).all() and (c1[:, 148:] == 0).all()
 
 
 def test_metric_oracle_and_summary_split():

@@ -8,7 +8,9 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+from oracle import adapter as oadapter  # noqa: E402
 from oracle import cgeom, geom, nets  # noqa: E402
+from _measure import check  # noqa: E402
 
 T = torch.from_numpy
 
@@ -401,17 +403,21 @@ def test_tps(ops, golden_ops):
     out, Tm, idx = ops.tps_transform(dev(U), dev(src), dev(tgt), (24, 28), want_idx=True)
     ref_out, ref_T = geom.tps_transformer(U, src, tgt, (24, 28))
     relT = (Tm.cpu() - ref_T).abs().max().item() / max(1.0, ref_T.abs().max().item())
-    assert relT < 1e-4, relT                     # fp64 solve of a 172x172 system whose entries were rounded to fp32 first
+    check("tps_T_rel", relT, 1e-4)               # fp64 solve of a 172x172 system whose entries were rounded to fp32 first
     # the oracle's own sample indices from its T and grid (same _interpolate arithmetic as the homography transformer)
-    ref_idx = geom.tps_indices(src, ref_T, U.shape[-2:], (24, 28))
+    ref_idx, frac = geom.tps_indices(src, ref_T, U.shape[-2:], (24, 28), return_frac=True)
     mism = (idx.cpu() != ref_idx).any(-1)
+    near = frac < 1e-4                            # a sample coordinate within 1e-4 px of an integer may floor either way (same
+    #                                               exemption style as the occlusion threshold test): logf differs in the last bit
+    check("tps_idx_mismatches_off_integer", int((mism & ~near).sum()), 0, inclusive=True)
     d = (out.cpu() - T(golden_ops["tps_out"])).abs()
     same = ~mism[:, None].expand_as(d)
     print(f"[tps] T rel {relT:.2e}; idx mismatches {int(mism.sum())} / {mism.numel()}; |out - golden| max {d.max():.3e} "
           f"(where idx agree: {d[same].max():.3e})")
-    assert mism.float().mean() < 5e-3, int(mism.sum())
+    check("tps_idx_mismatches_total", int(mism.sum()), int(near.sum()), inclusive=True)
     # same 4 taps, weights from coordinates that agree to ~1e-4 px, on a 0..255 NOISE image (|gradient| up to 255 / px)
-    assert d[same].max() < 0.2 and np.percentile(d.numpy(), 99) < 5e-2, (d[same].max(), np.percentile(d.numpy(), 99))
+    check("tps_out_same_taps_max", d[same].max(), 0.1)      # measured 0.0768
+    check("tps_out_p99", np.percentile(d.numpy(), 99), 5e-2)
 
 
 def test_blend_and_eval_finish(ops):
@@ -429,19 +435,14 @@ def test_blend_and_eval_finish(ops):
             homo1[:, 3:, :20] = 0; homo2[:, 3:, :30] = 0; fin[:, 3:, :25] = 0; homo1[:, 3:, 40:] = 1
         occ = (torch.rand(1, 1, h, w, generator=gg) > 0.3).float()
         f = fin * occ
-        o1, m1 = homo1[:, :3], homo1[:, 3:]
-        o2, m2 = f[:, :3], f[:, 3:]
-        nov = 1 - m1
-        o2r = homo2[:, :3] * (1 - m2) * nov + o2 * m2                              # oracle/adapter.py:99-100
-        m2r = homo2[:, 3:] * (1 - m2) * nov + m2 * m2
-        bl = torch.nan_to_num(((o1 * m1 + o2r * m2r) / (m1 + m2r)).clip(0, 255), nan=0.0).to(torch.uint8)
+        _, o2r, m1r, m2r, bl = oadapter.blend_canvas(homo1, homo2, f)              # the oracle's restatement of :339-360
         find = dev(fin)
         go2, gm1, gm2, gbl = ops.blend(dev(homo1), dev(homo2), find, dev(occ))
         assert torch.equal(find.cpu(), f)
         assert torch.equal(go2.cpu(), o2r)
         assert torch.equal(gbl.cpu(), bl), (int((gbl.cpu() != bl).sum()), fractional)
-        assert torch.equal(gm1.cpu(), m1.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1))
-        assert torch.equal(gm2.cpu(), m2r.mean(1, keepdim=True).clip(0, 1).repeat(1, 3, 1, 1))
+        assert torch.equal(gm1.cpu(), m1r)
+        assert torch.equal(gm2.cpu(), m2r)
     fin6 = torch.rand(2, 6, h, w, generator=gg)
     occ2 = (torch.rand(2, 1, h, w, generator=gg) > 0.5).float()
     fd = dev(fin6)

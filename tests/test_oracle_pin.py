@@ -276,3 +276,26 @@ def test_mix_methods_oracle_vs_reference_golden(mname):
     assert np.array_equal(np.packbits((res["mask2"].numpy() >= 0.5).astype(np.uint8).reshape(-1)), g[f"mix_{mname}_mask2_bits"])
     a = res["inpaint_area_mask"].double()
     assert np.allclose([float(a.sum()), float((a * a).sum())], g[f"mix_{mname}_area_cs"], rtol=0, atol=0)
+
+
+def test_inverse_f64_plain_c():
+    """cgeom.inverse_f64 (Gauss-Jordan, plain C): the fp64 `torch.inverse` of the TPS system (torch_tps_transform.py:173)
+    without LAPACK -- the round-2 GPU-box failure was MKL's threaded batched dgetrf.  Against numpy on random and on a real
+    TPS system; and the oracle's T reproduces the torch.inverse path bit for bit on the golden control points."""
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(3, 60, 60))
+    Ai = cgeom.inverse_f64(A)
+    assert np.abs(Ai - np.linalg.inv(A)).max() < 1e-10 * np.abs(Ai).max()
+    assert np.abs(A @ Ai - np.eye(60)).max() < 1e-10
+    with pytest.raises(np.linalg.LinAlgError):
+        cgeom.inverse_f64(np.zeros((1, 4, 4)))
+    g = np.load(os.path.join(GOLDEN, "ops_small.npz"))
+    src, tgt = T(g["tps_source"]), T(g["tps_target"])
+    _, Tm = geom.tps_transformer(T(g["tps_U"]), src, tgt, (24, 28))
+    B, N, _ = src.shape
+    p = torch.cat([torch.ones(B, N, 1), src], 2)
+    d2 = ((p[:, :, None, :] - p[:, None, :, :]) ** 2).sum(3)
+    Wm = torch.cat([torch.cat([p, d2 * torch.log(d2 + 1e-6)], 2), torch.cat([torch.zeros(B, 3, 3), p.permute(0, 2, 1)], 2)], 1).double()
+    tp = torch.cat([tgt, torch.zeros(B, 3, 2)], 1).double()
+    T_ref = torch.stack([torch.matmul(torch.inverse(Wm[b]), tp[b]) for b in range(B)]).permute(0, 2, 1).float()   # one matrix at a time
+    assert (Tm - T_ref).abs().max() <= 1e-6 * T_ref.abs().max()
