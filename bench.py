@@ -117,7 +117,20 @@ def instrumented_step(run_step):
         torch.cuda.synchronize()
     finally:
         lib.st_set_gemm_observer(None, None)
-    return (sum(r[0] for r in rec), sum(r[2].elapsed_time(r[3]) for r in rec), len(rec), sum(r[1] for r in rec))
+    # what an EMPTY event bracket reads on this stream: two back-to-back records are ~2-3 us apart on the GPU timeline, and
+    # every bracket above carries that on top of its kernel(s); subtract the median
+    st = torch.cuda.current_stream()
+    empties = []
+    for _ in range(64):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        e1.record(st)
+        empties.append((e0, e1))
+    torch.cuda.synchronize()
+    ov = sorted(e0.elapsed_time(e1) for e0, e1 in empties)[len(empties) // 2]
+    raw = [r[2].elapsed_time(r[3]) for r in rec]
+    return dict(flops=sum(r[0] for r in rec), ms_raw=sum(raw), ms=sum(max(0.0, t - ov) for t in raw), launches=len(rec),
+                alg_bytes=sum(r[1] for r in rec), bracket_overhead_us=1e3 * ov)
 
 
 def corr_roofline(ops, B=8, N=4096, C=256, iters=10):
@@ -189,6 +202,8 @@ def worker(args):
     dist = None
     if args.dry_run:                                   # launcher + collective plumbing, CPU only
         import torch.distributed as dist
+        if world != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
         vals = torch.full((args.steps,), float(rank))
         gathered = [torch.empty_like(vals) for _ in range(world)]
@@ -200,6 +215,9 @@ def worker(args):
                               "gathered_ranks": sorted({int(g[0]) for g in gathered})}), flush=True)
         dist.destroy_process_group()
         return
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s): refusing to print "
+                         f"n_gpus={args.gpus} for a {world}-rank run")
     if args.share_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -268,6 +286,8 @@ def worker(args):
                 o = fwds[k](a, b)
                 return ops.masked_psnr_ssim(a, o["final_warp_output"])[0]      # evaluate.py:53-59 metric, HIP kernel, fp64 (psnr, ssim)
 
+    t_local_done, rank_times = [0.0], []
+
     def timed(nsteps, **kw):
         torch.cuda.synchronize()
         if dist:
@@ -285,12 +305,19 @@ def worker(args):
             gathered = [torch.empty_like(metric) for _ in range(world)]
             dist.all_gather(gathered, metric)          # the path's only collective: per-pair metric reduction
         torch.cuda.synchronize()
+        t_local_done[0] = time.perf_counter()
         if dist:
             dist.barrier()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], device="cuda")
         if dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # this rank's own time up to its last kernel (before the barrier): per-rank throughput spread of the N > 1 line
+        mine = torch.tensor([t_local_done[0] - t0], device="cuda")
+        per_rank = [torch.empty_like(mine) for _ in range(world)] if dist else [mine]
+        if dist:
+            dist.all_gather(per_rank, mine)
+        rank_times[:] = [t.item() for t in per_rank]
         return tmax.item()
 
     log("model built, warming up")
@@ -300,25 +327,29 @@ def worker(args):
         finish_one()
     log("timed region")
     dt = timed(args.steps)
+    per_rank_pairs_s = [args.steps * nb / t for t in rank_times]
     dt1 = None
     if nstreams > 1:
         dt1 = timed(max(10, args.steps // 2), n_in_flight=1)       # same graphs, one pair in flight (latency-bound figure)
 
     if rank == 0:
         log(f"timed region done: {dt:.3f} s for {args.steps} steps; instrumented step")
-        if big:
-            flops, gemm_ms, launches, abytes = instrumented_step(lambda: model(a, b, type="test_out"))
-        else:
-            flops, gemm_ms, launches, abytes = instrumented_step(lambda: model(a, b, type="test_eval"))
+        inst = instrumented_step((lambda: model(a, b, type="test_out")) if big else (lambda: model(a, b, type="test_eval")))
+        flops, gemm_ms, launches, abytes = inst["flops"], inst["ms"], inst["launches"], inst["alg_bytes"]
         tf = flops / gemm_ms / 1e9
         traffic, tsrc = None, None             # HBM bytes per step of the GEMM family from the committed PMC passes
-        for name in ("r2_traffic.json", "r1_traffic.json"):
+        for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and not big and nb == 1:
                 t = json.load(open(tpath))
                 traffic = t["fetch_bytes_per_step"] + t["write_bytes_per_step"]
                 tsrc = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied)"
                 break
+        # per-kernel time of the same command from the committed rocprofv3 pass (tools/prof_bench.sh -> profiles/r3_kernel_summary.json)
+        prof = None
+        ppath = os.path.join(ROOT, "profiles", "r3_kernel_summary.json")
+        if os.path.exists(ppath) and not big and nb == 1:
+            prof = json.load(open(ppath))
         wl = ("synthetic 1024x1024 pairs, 4 per GPU, batch=1, FlowHomoAdpater.forward(type=test_out)" if big else
               f"UDIS-D-shaped 512x512 pairs, batch={nb}, FlowHomoAdpater.forward(type=test_eval)")
         out = {
@@ -332,11 +363,23 @@ def worker(args):
                        "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective, one all_gather of per-pair metrics"
                                       + (" [REHEARSAL: all ranks share cuda:0]" if args.share_gpu else "")},
             "value_1_in_flight": None if dt1 is None else world * max(10, args.steps // 2) * nb / dt1,
+            "per_rank_pairs_per_s": {"min": min(per_rank_pairs_s), "max": max(per_rank_pairs_s), "ranks": len(per_rank_pairs_s)},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_dma_kernel + conv_gemm_kernel (fp32 MFMA implicit GEMM: all st_conv_gemm launches of one step)",
                          "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)", "traffic_source": tsrc,
                          "algorithmic_bytes": abytes, "launches_per_step": launches, "gflop_per_step": flops / 1e9,
-                         "kernel_ms_per_step": gemm_ms},
+                         "kernel_ms_per_step": gemm_ms, "kernel_ms_per_step_uncorrected": inst["ms_raw"],
+                         "event_bracket_overhead_us": inst["bracket_overhead_us"],
+                         "how": "HIP events around every launch of the family on one extra eager step (one pair in flight), minus the "
+                                "median reading of an empty event bracket; `frac` = family FLOPs / that time / peak.  ms_per_step is WALL "
+                                "time per pair with pairs_in_flight pairs overlapping on separate streams, so it can be smaller than the "
+                                "sum of one pair's kernel durations",
+                         # whole path: every kernel, launch gap and non-GEMM kernel included, from the timed region itself
+                         "whole_path_frac": (world * args.steps * nb / dt) / world * (flops / nb) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "kernel_ms_per_step_rocprof": None if prof is None else prof.get("gemm_family_ms_per_forward"),
+                         "frac_rocprof": None if prof is None else flops / 1e9 / prof["gemm_family_ms_per_forward"] / FP32_MFMA_PEAK_TFLOPS,
+                         "other_kernels_ms_per_step": None if prof is None else prof.get("other_kernels_ms_per_forward"),
+                         "rocprof_source": None if prof is None else prof.get("source")},
             "corr_volume": None if args.no_corr_roofline else corr_roofline(ops),
         }
         if world == 1 and not args.no_cpu_baseline:

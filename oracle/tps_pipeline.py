@@ -178,8 +178,12 @@ def _kernel_distance(sq, eps=1e-8):
     return 0.5 * sq * sq.add(eps).log()
 
 
-def get_tps_transform(points_src, points_dst):
-    """kornia.geometry.transform.get_tps_transform: [K P; P^T 0] [w; a] = [dst; 0], torch.linalg.solve."""
+def get_tps_transform(points_src, points_dst, solve_dtype=None):
+    """kornia.geometry.transform.get_tps_transform: [K P; P^T 0] [w; a] = [dst; 0], torch.linalg.solve.
+
+    solve_dtype=torch.float64 solves the SAME fp32 system in fp64 (a control, not the reference's arithmetic): near-coincident
+    control points make the system ill-conditioned (cond ~ 1e7 on real canvases), and then the reference's fp32 LU result
+    depends on the LAPACK build (tests/test_oracle_pin.py::test_tps_fp32_solve_is_lapack_dependent)."""
     B, N = points_src.shape[:2]
     K = _kernel_distance(_pair_square_euclidean(points_src, points_dst))
     zero = torch.zeros(B, 3, 3, dtype=points_src.dtype)
@@ -188,7 +192,7 @@ def get_tps_transform(points_src, points_dst):
     P = torch.cat((one, points_src), -1)
     Pt = torch.cat((P, zero), 1).transpose(1, 2)
     L = torch.cat((torch.cat((K, P), -1), Pt), 1)
-    w = torch.linalg.solve(L, dest)
+    w = torch.linalg.solve(L, dest) if solve_dtype is None else torch.linalg.solve(L.to(solve_dtype), dest.to(solve_dtype)).to(L.dtype)
     return w[:, :-3], w[:, -3:]
 
 
@@ -214,13 +218,13 @@ def warp_image_tps(image, centers, kernel_weights, affine_weights, align_corners
     return F.grid_sample(image, warped, align_corners=align_corners)
 
 
-def warp_by_tps(H_warp, H_warp_mask, points_src, points_dst, out_height, out_width, kernel_scale=1.0, affine_scale=1.0):
+def warp_by_tps(H_warp, H_warp_mask, points_src, points_dst, out_height, out_width, kernel_scale=1.0, affine_scale=1.0, solve_dtype=None):
     """'kornia' branch of tps_pipline.py:362-378: points / (out_width, out_height) through float64 and back."""
     x = torch.cat((H_warp, H_warp_mask), dim=1)
     ps, pd = points_src.to(torch.float64), points_dst.to(torch.float64)
     ps = torch.stack([ps[:, :, 0] / out_width, ps[:, :, 1] / out_height], 2).to(torch.float32)
     pd = torch.stack([pd[:, :, 0] / out_width, pd[:, :, 1] / out_height], 2).to(torch.float32)
-    kw, aw = get_tps_transform(pd, ps)                       # the reverse transform: dst -> src
+    kw, aw = get_tps_transform(pd, ps, solve_dtype)          # the reverse transform: dst -> src
     return warp_image_tps(x, ps, kw * kernel_scale, aw * affine_scale, align_corners=False)
 
 
@@ -237,7 +241,7 @@ def erode_dilate(x, k=11):
 
 
 # ------------------------------------------------------------------ pipeline (tps_pipline.py:20-205, inpaint_fn=None)
-def tps_H_warp(inputs, image_limit, cfg):
+def tps_H_warp(inputs, image_limit, cfg, solve_dtype=None):
     """inputs: dict(output1, mask1, H_warp, H_warp_mask, final_warp, mask2, residual_flow, valid, occlusion_mask,
     border_points_mask); image_limit: dict(width_min, height_min, out_height, out_width); cfg: TPS_PIPELINE_CONFIG."""
     out_h, out_w = image_limit["out_height"], image_limit["out_width"]
@@ -256,7 +260,7 @@ def tps_H_warp(inputs, image_limit, cfg):
         keep = [i for i in range(src.shape[1]) if m[int(ps[0, i, 1]), int(ps[0, i, 0])] == 1]
         keep = torch.tensor(keep, dtype=torch.long)
         ps, pd = ps[:, keep, :], pd[:, keep, :]
-    both = warp_by_tps(inputs["H_warp"], inputs["H_warp_mask"], ps, pd, out_h, out_w, cfg.kernel_scale, cfg.affine_scale)
+    both = warp_by_tps(inputs["H_warp"], inputs["H_warp_mask"], ps, pd, out_h, out_w, cfg.kernel_scale, cfg.affine_scale, solve_dtype)
     tps, tmask = both[:, 0:3], both[:, 3:]
     tmask = (tmask.mean(dim=1, keepdim=True) >= 0.5).float()
     tmask = 1.0 - erode_dilate(1.0 - tmask, 11)                           # :143-150
@@ -362,9 +366,9 @@ def mix_inpaint_all_area(tps_H_warp, tps_H_warp_mask, output1, mask1, final_warp
     return tfw, tfwm, inpaint_img, inpaint_img_mask, iam
 
 
-def tps_H_warp_with_inpaint(inputs, image_limit, cfg, mix_fn, inpainter=None):
+def tps_H_warp_with_inpaint(inputs, image_limit, cfg, mix_fn, inpainter=None, solve_dtype=None):
     """tps_pipline.py:20-205 with inpaint_fn = mix_fn(..., inpainter=...) (out.py:235-236): :178-188."""
-    res = tps_H_warp(inputs, image_limit, cfg)
+    res = tps_H_warp(inputs, image_limit, cfg, solve_dtype)
     assert cfg.output2_is_only_tps
     output1, mask1 = inputs["output1"], inputs["mask1"]
     tfw, tfwm, inpaint_img, inpaint_img_mask, inpaint_area_mask = mix_fn(

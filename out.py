@@ -35,6 +35,8 @@ def get_config(argv=None):
     p.add_argument("--inf_cfg", type=str, default="all_img1_with_inpaint_g12_transRef")
     p.add_argument("--gpu", type=int, default=0)
     p.add_argument("--skip_if_avg_fusion_exists", action="store_true")
+    p.add_argument("--dry-run", dest="dry_run", action="store_true",
+                   help="list the pairs this rank would process (sharding rehearsal: no model, no GPU) and exit")
     args = p.parse_args(argv)
     import stitch_amd
     cfg, tps = stitch_amd.load_inference_config(args.inf_cfg, args.model_config_name)
@@ -125,7 +127,8 @@ def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_m
     new = stitch_amd.tps_pipeline.tps_H_warp(inputs, limit, tpc, inpaint_fn=inpaint_fn)
     out = dict(out, forward_output2=out["output2"], forward_mask2=out["mask2"], forward_blend_image=out["blend_image"],
                new_blend_image=new["new_blend_image"], tps_output=new["tps_output"], output2=new["output2"],
-               mask2=new["mask2"].repeat(1, 3, 1, 1))
+               mask2=new["mask2"] if new["mask2"].shape[1] == 3 else new["mask2"].expand(-1, 3, -1, -1))   # 1 channel normally; the
+    #                      mix_fn branch "inpaint result all zero: not used" returns a 3-channel mask (reference: passed through as is)
     to_pillow(out["H_warp"]).save(result_path + "H_warp.jpg")
     to_pillow(out["final_warp"]).save(result_path + "flow_warp.jpg")
     to_pillow(out["output1"]).save(result_path + "warp1.jpg")
@@ -147,10 +150,29 @@ def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_m
     return out, result_path
 
 
+def shard_of_this_rank(data, rank, world):
+    """Pairs are independent: under ``torchrun --nproc-per-node N out.py ...`` rank r takes pairs r, r + N, ... of the list
+    (`stitch_amd.dist.shard_indices`; replaces the reference's single-process nn.DataParallel, out.py:80) and every rank
+    writes its own result directories; no collective is needed."""
+    from stitch_amd import dist as sdist
+    return [data[i] for i in sdist.shard_indices(len(data), rank, world)]
+
+
 def main(argv=None):
     import stitch_amd
+    from stitch_amd import dist as sdist
     cfg = get_config(argv)
-    torch.cuda.set_device(cfg.gpu)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if getattr(cfg, "dry_run", False):
+        rank = int(os.environ.get("RANK", "0"))
+        mine = shard_of_this_rank(get_data_dict_list(cfg.data_root_path, cfg.txt_file), rank, world)
+        print("DRY_RUN rank", rank, "of", world, "pairs", [os.path.basename(os.path.normpath(d["DATA_PATH"])) for d in mine], flush=True)
+        return None
+    if world > 1:
+        rank, world, local = sdist.init()              # one process per GPU: binds this process to cuda:LOCAL_RANK
+    else:
+        rank, local = 0, cfg.gpu
+        torch.cuda.set_device(cfg.gpu)
     model = stitch_amd.build_model(cfg)
     if cfg.restore_ckpt:
         model.load_state_dict(torch.load(cfg.restore_ckpt, map_location="cpu", weights_only=True), strict=True)
@@ -175,12 +197,16 @@ def main(argv=None):
     os.makedirs(save_root, exist_ok=True)
     with open(save_root + "config.txt", "w") as f:
         f.write(repr(dict(cfg)))
-    for dd in get_data_dict_list(cfg.data_root_path, cfg.txt_file):
+    for dd in shard_of_this_rank(get_data_dict_list(cfg.data_root_path, cfg.txt_file), rank, world):
         if cfg.skip_if_avg_fusion_exists and os.path.exists(os.path.join(save_root, os.path.basename(os.path.normpath(dd["DATA_PATH"])), "ave_fusion.jpg")):
             print("[WARNING] Skip, Due to exist", dd["DATA_PATH"])
             continue
         _, rp = inference_one_data(cfg, dd, save_root, model, composition_model, inpainter)
         print("saved", rp)
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
     return save_root
 
 

@@ -9,15 +9,30 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment; returns (rank, world_size, local_rank)."""
+def init(backend=None, expect_world=None):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world_size, local_rank).
+
+    With a GPU backend the process is bound to ITS GPU here (``torch.cuda.set_device(local_rank)`` and ``device_id=`` for the
+    process group), not left to the caller: RCCL then opens its communicator on the right device eagerly and a stray
+    ``cuda:0`` default cannot put every rank on one GPU.  ``expect_world``: fail loudly when the launcher started a
+    different number of ranks than the caller asked for (a silent 1-rank run must not report N GPUs)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if expect_world is not None and int(expect_world) != world:
+        raise RuntimeError(f"launched with WORLD_SIZE={world} but {expect_world} ranks were requested")
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    gpu = backend == "nccl"
+    if gpu:
+        if local >= torch.cuda.device_count():
+            raise RuntimeError(f"LOCAL_RANK={local} but only {torch.cuda.device_count()} GPU(s) are visible: one process per GPU")
+        torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local) if gpu else None)
+    if dist.is_initialized() and dist.get_world_size() != world:
+        raise RuntimeError(f"process group has {dist.get_world_size()} ranks, environment says {world}")
     return rank, world, local
 
 

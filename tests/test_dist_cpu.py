@@ -68,3 +68,30 @@ def test_bench_launcher_starts_n_ranks():
     assert len(lines) == 1, lines
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["gathered_ranks"] == [0, 1]
+
+
+def test_out_py_shards_its_pair_list(tmp_path):
+    """`torchrun --nproc-per-node 2 out.py ...` (configs[4] names 8 GPUs): every rank takes pairs rank, rank + N, ... of
+    demo.txt; rehearsed with --dry-run (no model, no GPU).  The shards are disjoint and cover the list."""
+    import ast
+    names = [f"pair{i:02d}" for i in range(5)]
+    (tmp_path / "demo.txt").write_text("\n".join(names) + "\n")
+    seen = {}
+    for r in range(2):
+        env = dict({k: v for k, v in os.environ.items() if k not in ("MASTER_PORT",)}, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "out.py"), "--data_root_path", str(tmp_path) + "/", "--dry-run"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("DRY_RUN")][0]
+        seen[r] = ast.literal_eval(line.split("pairs", 1)[1].strip())
+    assert seen[0] == names[0::2] and seen[1] == names[1::2]
+
+
+def test_init_refuses_a_world_size_mismatch(monkeypatch):
+    from stitch_amd import dist as sd
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    import pytest
+    with pytest.raises(RuntimeError):
+        sd.init(backend="gloo", expect_world=8)
+    assert sd.init(backend="gloo", expect_world=1) == (0, 1, int(os.environ.get("LOCAL_RANK", "0")))

@@ -18,3 +18,8 @@ for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
     if ms >= 0.004:
         print(f"{ms:8.3f} ms  x{int(r['Calls']) / fw:7.1f}  avg {float(r['AverageNs']) / 1e3:8.1f} us  {short(r['Name'])}")
 print(f"total kernel time per forward {tot:.3f} ms; GEMM family {gemm:.3f} ms; other {tot - gemm:.3f} ms")
+if len(sys.argv) > 3:          # python tools/kernel_stats_summary.py STATS.csv FORWARDS OUT.json
+    import json
+    json.dump(dict(forwards=fw, total_kernel_ms_per_forward=tot, gemm_family_ms_per_forward=gemm, other_kernels_ms_per_forward=tot - gemm,
+                   source="rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-corr-roofline (3 pairs in flight; "
+                          "kernels of different pairs overlap, so per-kernel durations include contention)"), open(sys.argv[3], "w"), indent=1)
