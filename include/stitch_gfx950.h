@@ -291,10 +291,13 @@ int st_gather_points(const float* planes, const int32_t* points_xy, float* out, 
  * work_f64: (n+3)*(n+6) doubles.  mode 0 = kornia get_tps_transform(points_src = sites, points_dst = centers = values) as
  * called by warp_by_tps (tps_pipline.py:362-378, kornia_tps.py:47-112): normalised points, U = 0.5 d2 log(d2 + 1e-8);
  * mode 1 = pixel-unit r^2 log r^2 spline with centers = sites (OpenCV ThinPlateSplineShapeTransformer's formulation,
- * opencv_tps.py:8-18).                                                                                                  */
+ * opencv_tps.py:8-18).  status (device int32, may be NULL): 0, or 1 when a pivot collapsed to rounding level (coincident or
+ * collinear control points: the reference's torch.linalg.solve raises there) -- the weights are then meaningless.       */
 int st_tps2_solve(const float* sites, const float* centers, const float* values, void* work_f64, float* kernel_w,
-                  float* affine_w, int32_t n, int32_t mode, void* stream);
-/* warp_image_tps (kornia_tps.py:114-176): img [C,H,W] -> out [C,H,W]; centers [n,2]; grid_sample(bilinear, zeros).       */
+                  float* affine_w, int32_t n, int32_t mode, int32_t* status, void* stream);
+/* warp_image_tps (kornia_tps.py:114-176): img [C,H,W] -> out [C,H,W]; centers [n,2]; grid_sample(bilinear, zeros).  mode 0 =
+ * kornia (normalised mesh), 1 = pixel-unit spline sampled directly, 3 = 1 on uint8 data as the reference's OpenCV branch sees it
+ * (opencv_tps.py + utils.py:10: taps truncated to 0..255 integers, result rounded half-to-even and saturated).            */
 int st_tps2_warp(const float* img, const float* centers, const float* kernel_w, const float* affine_w, float* out,
                  int32_t C, int32_t H, int32_t W, int32_t n, float kernel_scale, float affine_scale,
                  int32_t align_corners, int32_t mode, void* stream);

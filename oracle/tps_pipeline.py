@@ -23,6 +23,7 @@ The reference's default back-end (OpenCV ThinPlateSplineShapeTransformer) and it
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -238,6 +239,47 @@ def _rect_filter(x, k, take_max):
 
 def erode_dilate(x, k=11):
     return _rect_filter(_rect_filter(x, k, False), k, True)
+
+
+def warp_by_tps_opencv_like(H_warp, H_warp_mask, points_src, points_dst):
+    """'opencv' branch of warp_by_tps (tps_pipline.py:380-385 -> tps_methods/opencv_tps.py:8-18,59-68) as far as it can be
+    restated without OpenCV (NOT importable here: the spline fit and cv2's fixed-point remap are unpinned against cv2):
+      * `to_pillow_fn` (core/inference/utils.py:10) truncates image AND mask to uint8 before cv2 sees them;
+      * `estimateTransformation(target, source)` + `warpImage`: the r^2 log r^2 thin-plate spline in pixel units that maps an
+        output pixel (a target/dst site) to its source position, sampled bilinearly with a constant 0 border; coincident sites
+        keep their first occurrence; kernel_scale / affine_scale are not used on this branch;
+      * the result is uint8 (rounded half-to-even, saturated) and comes back as float.
+    fp64 throughout (exact reference for the HIP kernel's fp32 evaluation)."""
+    x = torch.cat((H_warp, H_warp_mask), dim=1).to(torch.uint8).double()
+    a, b = points_dst[0].double().numpy(), points_src[0].double().numpy()
+    _, first = np.unique(a.astype(np.float32), axis=0, return_index=True)
+    first = np.sort(first)
+    a, b = a[first], b[first]
+    n = a.shape[0]
+
+    def U(p, q):
+        d2 = ((p[:, None, :] - q[None, :, :]) ** 2).sum(-1)
+        return d2 * np.log(d2 + 1.1920929e-7)
+    L = np.zeros((n + 3, n + 3))
+    L[:n, :n] = U(a.astype(np.float32).astype(np.float64), a.astype(np.float32).astype(np.float64))
+    L[:n, n], L[:n, n + 1:] = 1.0, a
+    L[n, :n], L[n + 1:, :n] = 1.0, a.T
+    w = np.linalg.solve(L, np.concatenate([b, np.zeros((3, 2))], 0))
+    _, C, H, W = x.shape
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    g = np.stack([xs.ravel(), ys.ravel()], 1)
+    m = U(g, a) @ w[:n] + w[n][None] + g @ w[n + 1:]
+    ix, iy = m[:, 0], m[:, 1]
+    x0, y0 = np.floor(ix), np.floor(iy)
+    out = np.zeros((C, H * W))
+    im = x[0].numpy().reshape(C, -1)
+    for dx, dy, wt in ((0, 0, (x0 + 1 - ix) * (y0 + 1 - iy)), (1, 0, (ix - x0) * (y0 + 1 - iy)), (0, 1, (x0 + 1 - ix) * (iy - y0)), (1, 1, (ix - x0) * (iy - y0))):
+        xx, yy = x0 + dx, y0 + dy
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        idx = (np.where(ok, yy, 0) * W + np.where(ok, xx, 0)).astype(np.int64)
+        out += np.where(ok, wt, 0.0)[None] * im[:, idx]
+    out = np.clip(np.rint(out), 0, 255)
+    return torch.from_numpy(out.reshape(1, C, H, W)).float()
 
 
 # ------------------------------------------------------------------ pipeline (tps_pipline.py:20-205, inpaint_fn=None)

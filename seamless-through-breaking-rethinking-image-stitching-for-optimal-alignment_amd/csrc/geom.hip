@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(const float* __restrict_
         v = __fmaf_rn(xin1 && yin0 ? im[(size_t)y0 * W + x1] : 0.f, ne, v);
         v = __fmaf_rn(xin0 && yin1 ? im[(size_t)y1 * W + x0] : 0.f, sw, v);
         v = __fmaf_rn(xin1 && yin1 ? im[(size_t)y1 * W + x1] : 0.f, se, v);
+        if (!fin) v = 0.f;                               // non-finite coordinate: ATen's bounds tests all fail -> 0 (0 * NaN weights would give NaN)
         out[((size_t)b * C + c) * hw + pix] = mul ? v * m : v;
     }
 }

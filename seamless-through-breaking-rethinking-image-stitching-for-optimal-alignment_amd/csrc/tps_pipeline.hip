@@ -169,12 +169,14 @@ __device__ __forceinline__ float tps2_u(float ax, float ay, float bx, float by, 
 // whose operation order is not reproducible; the fp64 solve is the exact solution of the same fp32 system.)
 __global__ __launch_bounds__(256) void tps2_solve_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
                                                          const float* __restrict__ rhs, double* __restrict__ work_g,
-                                                         float* __restrict__ kw, float* __restrict__ aw, int n, int mode, int use_lds) {
+                                                         float* __restrict__ kw, float* __restrict__ aw, int n, int mode, int use_lds,
+                                                         int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double tps2_lds[];
     double* __restrict__ work = use_lds ? tps2_lds : work_g;       // n <= ~130: the augmented matrix lives in LDS (91 pivot steps
                                                                    // of global round trips cost 1.9 ms; in LDS 0.2 ms)
     const int n3 = n + 3, ld = n + 5;
     __shared__ int s_piv;
+    __shared__ double s_pmin, s_pmax;             // smallest / largest pivot magnitude: singular-system detection
     __shared__ double s_best[4];
     __shared__ int s_idx[4];
     __shared__ double s_fac_lds[144];             // per-row elimination factors: LDS mode has n + 3 <= 140
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(256) void tps2_solve_kernel(const float* __restrict
         }
         work[e] = v;
     }
+    if (threadIdx.x == 0) { s_pmin = 1e300; s_pmax = 0.0; }
     __syncthreads();
     for (int c = 0; c < n3; ++c) {
         double best = -1.0;
@@ -215,6 +218,8 @@ __global__ __launch_bounds__(256) void tps2_solve_kernel(const float* __restrict
             int ii = s_idx[0];
             for (int t = 1; t < 4; ++t) if (s_best[t] > bb || (s_best[t] == bb && s_idx[t] < ii)) { bb = s_best[t]; ii = s_idx[t]; }
             s_piv = ii;
+            if (!(bb >= s_pmin)) s_pmin = bb;        // (a NaN pivot lands here too)
+            if (bb > s_pmax) s_pmax = bb;
         }
         __syncthreads();
         const int piv = s_piv;
@@ -227,7 +232,8 @@ __global__ __launch_bounds__(256) void tps2_solve_kernel(const float* __restrict
         __syncthreads();
         // elimination of column c from every other row, parallel over all (row, column) elements of the trailing block:
         // factors first (they read column c, which the update does not touch), then one flat pass
-        const double inv = 1.0 / work[(size_t)c * ld + c];
+        const double pv = work[(size_t)c * ld + c];
+        const double inv = 1.0 / (pv != 0.0 ? pv : 1.0);             // a zero pivot is reported through `status`; keep the sweep finite
         for (int r = threadIdx.x; r < n3; r += 256) s_fac[r] = (r == c) ? 0.0 : work[(size_t)r * ld + c] * inv;
         __syncthreads();
         const int wcols = ld - (c + 1);
@@ -244,24 +250,30 @@ __global__ __launch_bounds__(256) void tps2_solve_kernel(const float* __restrict
         if (r < n) { kw[2 * r] = wx; kw[2 * r + 1] = wy; }
         else { aw[2 * (r - n)] = wx; aw[2 * (r - n) + 1] = wy; }
     }
+    // coincident control points (two equal rows) or fewer than three non-collinear ones: a pivot collapses to rounding level
+    if (threadIdx.x == 0 && status) status[0] = (s_pmin == s_pmin && s_pmin > 1e-13 * s_pmax) ? 0 : 1;
 }
 
 extern "C" int st_tps2_solve(const float* sites, const float* centers, const float* values, void* work_f64, float* kernel_w,
-                             float* affine_w, int32_t n, int32_t mode, void* stream) {
+                             float* affine_w, int32_t n, int32_t mode, int32_t* status, void* stream) {
     if (!sites || !centers || !values || !work_f64 || !kernel_w || !affine_w || n < 3 || n > 4096) return ST_EINVAL;
     const size_t bytes = (size_t)(n + 3) * (n + 5) * sizeof(double);
     const int use_lds = bytes <= 150 * 1024 && n + 3 <= 144;
     if (use_lds && bytes > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)tps2_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipLaunchKernelGGL(tps2_solve_kernel, dim3(1), dim3(256), use_lds ? bytes : 0, (hipStream_t)stream, sites, centers, values,
-                       (double*)work_f64, kernel_w, affine_w, n, mode, use_lds);
+                       (double*)work_f64, kernel_w, affine_w, n, mode & 1, use_lds, status);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
 
 // warp_image_tps (kornia_tps.py:114-176): coords = create_meshgrid(h, w) in [-1, 1]; warped = sum_i U(coord, center_i) w_i +
 // coord . A[1:3] + A[0]; grid_sample(bilinear, zeros, align_corners).  mode 1: coords are pixel indices, the result is a
-// source pixel position sampled directly (cv2.remap INTER_LINEAR, constant 0 border).
+// source pixel position sampled directly (cv2.remap INTER_LINEAR, constant 0 border).  mode 3 = mode 1 on uint8 data as the
+// reference's OpenCV branch sees it (core/inference/tps_methods/opencv_tps.py: `to_pillow_fn` = `.to(torch.uint8)` truncates
+// image AND mask before cv2's warpImage, which returns uint8): every tap is truncated toward zero and clamped to 0..255, the
+// result is rounded half-to-even and saturated (cv::saturate_cast<uchar>).  cv2's fixed-point interpolation itself (5-bit
+// coordinate fractions, 15-bit weights) is not restated: parity vs OpenCV unpinned.
 __global__ __launch_bounds__(256) void tps2_warp_kernel(const float* __restrict__ img, const float* __restrict__ centers,
                                                         const float* __restrict__ kw, const float* __restrict__ aw,
                                                         float* __restrict__ out, int C, int H, int W, int n, float kscale,
@@ -273,6 +285,8 @@ __global__ __launch_bounds__(256) void tps2_warp_kernel(const float* __restrict_
     __syncthreads();
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
+    const bool quant = mode & 2;
+    mode &= 1;
     float cx, cy;
     if (mode == 1) { cx = (float)x; cy = (float)y; }
     else {
@@ -301,10 +315,18 @@ __global__ __launch_bounds__(256) void tps2_warp_kernel(const float* __restrict_
     const size_t hw = (size_t)H * W;
     for (int c = 0; c < C; ++c) {
         const float* im = img + (size_t)c * hw;
-        float v = (xin0 && yin0 ? im[(size_t)y0 * W + x0] : 0.f) * nw;
-        v = __fmaf_rn(xin1 && yin0 ? im[(size_t)y0 * W + x1] : 0.f, ne, v);
-        v = __fmaf_rn(xin0 && yin1 ? im[(size_t)y1 * W + x0] : 0.f, sw, v);
-        v = __fmaf_rn(xin1 && yin1 ? im[(size_t)y1 * W + x1] : 0.f, se, v);
+        float t00 = xin0 && yin0 ? im[(size_t)y0 * W + x0] : 0.f, t01 = xin1 && yin0 ? im[(size_t)y0 * W + x1] : 0.f;
+        float t10 = xin0 && yin1 ? im[(size_t)y1 * W + x0] : 0.f, t11 = xin1 && yin1 ? im[(size_t)y1 * W + x1] : 0.f;
+        if (quant) {
+            t00 = fminf(fmaxf(truncf(t00), 0.f), 255.f); t01 = fminf(fmaxf(truncf(t01), 0.f), 255.f);
+            t10 = fminf(fmaxf(truncf(t10), 0.f), 255.f); t11 = fminf(fmaxf(truncf(t11), 0.f), 255.f);
+        }
+        float v = t00 * nw;
+        v = __fmaf_rn(t01, ne, v);
+        v = __fmaf_rn(t10, sw, v);
+        v = __fmaf_rn(t11, se, v);
+        if (!fin) v = 0.f;                               // non-finite coordinate: no tap is in range
+        if (quant) v = fminf(fmaxf(rintf(v), 0.f), 255.f);
         out[(size_t)c * hw + (size_t)y * W + x] = v;
     }
 }

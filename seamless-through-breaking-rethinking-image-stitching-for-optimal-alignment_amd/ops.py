@@ -7,6 +7,7 @@ import ctypes as C
 import torch
 
 from ._lib import GemmDesc, check, lib
+from ._lib import StitchError as StitchErrorBase
 
 ACT = dict(none=0, relu=1, gelu=2, sigmoid=3, tanh=4)
 EPI = dict(store=0, add=1, mul=2, gru=3, axpy=4, zr=5)
@@ -486,25 +487,33 @@ def gather_points(planes, points_xy):
     return out
 
 
+class SingularTPSError(StitchErrorBase):
+    """the TPS system of the control points has no unique solution (the reference's torch.linalg.solve raises there)"""
+
+
 def tps2_solve(sites, centers, values, mode=0):
     n = sites.shape[0]
     dev = sites.device
     work = torch.empty(((n + 3) * (n + 6),), device=dev, dtype=torch.float64)
     kw = torch.empty((n, 2), device=dev, dtype=torch.float32)
     aw = torch.empty((3, 2), device=dev, dtype=torch.float32)
-    check(lib.st_tps2_solve(_pc(sites), _pc(centers), _pc(values), _p(work), _p(kw), _p(aw), n, mode, _stream()), "st_tps2_solve")
+    status = torch.zeros((1,), device=dev, dtype=torch.int32)
+    check(lib.st_tps2_solve(_pc(sites), _pc(centers), _pc(values), _p(work), _p(kw), _p(aw), n, mode, _p(status), _stream()), "st_tps2_solve")
+    if int(status.item()):                     # (the post-pipeline already round-trips to the host for its control points)
+        raise SingularTPSError(f"singular TPS system: {n} control points with coincident or collinear sites")
     return kw, aw
 
 
 def tps2_warp(img, points_a, points_b, kernel_scale=1.0, affine_scale=1.0, mode=0, align_corners=False, weights=None):
     """TPS warp of img [1,C,H,W] by the spline with f(points_a_i) = points_b_i.  mode 0 (kornia): (kw, aw) =
-    get_tps_transform(points_a, points_b), kernel centres = points_b; mode 1 (pixel units): centres = points_a."""
+    get_tps_transform(points_a, points_b), kernel centres = points_b; mode 1 (pixel units): centres = points_a; mode 3: mode 1 on
+    uint8-quantised data (taps truncated to 0..255 integers, result rounded and saturated: what cv2 sees in the reference)."""
     B, Cc, H, W = img.shape
     assert B == 1
     dev = img.device
     a, b = points_a.float().contiguous().to(dev), points_b.float().contiguous().to(dev)
-    centers = b if mode == 0 else a
-    kw, aw = weights if weights is not None else tps2_solve(a, centers, b, mode)
+    centers = b if (mode & 1) == 0 else a
+    kw, aw = weights if weights is not None else tps2_solve(a, centers, b, mode & 1)
     out = torch.empty_like(img)
     check(lib.st_tps2_warp(_pc(img), _pc(centers), _pc(kw), _pc(aw), _p(out), Cc, H, W, b.shape[0], float(kernel_scale),
                            float(affine_scale), int(align_corners), mode, _stream()), "st_tps2_warp")

@@ -132,15 +132,28 @@ def warp_by_tps(H_warp, H_warp_mask, points_src, points_dst, out_height, out_wid
         # limit / occlusion filter): the reference's solvers are singular here; leave the homography warp as it is
         print(f"[tps_pipeline] only {points_src.shape[1]} control point(s) left: TPS warp skipped (identity)")
         return x
-    if tps_method == "kornia":
-        ps, pd = points_src.to(torch.float64), points_dst.to(torch.float64)
-        ps = torch.stack([ps[:, :, 0] / out_width, ps[:, :, 1] / out_height], 2).to(torch.float32)
-        pd = torch.stack([pd[:, :, 0] / out_width, pd[:, :, 1] / out_height], 2).to(torch.float32)
-        return ops.tps2_warp(x, pd[0], ps[0], kernel_scale, affine_scale, mode=0)      # get_tps_transform(dst, src), centres = src
-    if tps_method == "opencv":
-        # estimateTransformation(target, source) + warpImage: the spline that maps an output pixel to its source pixel,
-        # control points points_dst -> points_src, pixel units
-        return ops.tps2_warp(x, points_dst[0].float(), points_src[0].float(), kernel_scale, affine_scale, mode=1)
+    try:
+        if tps_method == "kornia":
+            ps, pd = points_src.to(torch.float64), points_dst.to(torch.float64)
+            ps = torch.stack([ps[:, :, 0] / out_width, ps[:, :, 1] / out_height], 2).to(torch.float32)
+            pd = torch.stack([pd[:, :, 0] / out_width, pd[:, :, 1] / out_height], 2).to(torch.float32)
+            return ops.tps2_warp(x, pd[0], ps[0], kernel_scale, affine_scale, mode=0)      # get_tps_transform(dst, src), centres = src
+        if tps_method == "opencv":
+            # tensor2WarpImage_TPS (opencv_tps.py): `to_pillow_fn` truncates image AND mask to uint8 before cv2 sees them (a
+            # bilinear mask edge < 1 becomes 0), estimateTransformation(target, source) + warpImage return uint8, and
+            # kernel_scale / affine_scale are not used on this branch: mode 3 = the pixel-unit spline on uint8-quantised data.
+            # Coincident sites (advanced_uniform_multi concatenates point sets) make the spline singular: keep the first of each
+            a, b = points_dst[0].float(), points_src[0].float()
+            _, first = np.unique(a.cpu().numpy(), axis=0, return_index=True)
+            if len(first) < a.shape[0]:
+                keep = torch.from_numpy(np.sort(first))
+                a, b = a[keep], b[keep]
+            return ops.tps2_warp(x, a, b, 1.0, 1.0, mode=3)
+    except ops.SingularTPSError as e:
+        # the reference's solvers raise (kornia: torch.linalg.solve) or return garbage (cv2) on a singular system; a NaN canvas
+        # would silently blank the blend, so leave the homography warp as it is and say so
+        print(f"[tps_pipeline] {e}: TPS warp skipped (identity)")
+        return x
     raise NotImplementedError(f"tps_method={tps_method!r}: only 'kornia' (pinned) and 'opencv' (native pixel-unit spline) are built")
 
 

@@ -368,6 +368,15 @@ def test_flow_warp_resize(ops, golden_ops):
     assert (out2.cpu() - T(golden_ops["warp_out"]) * mul).abs().max() < 1e-3
     big = fij * 50                                                          # mostly out of bounds
     assert (ops.flow_warp(dev(x), dev(big)).cpu() - geom.warp(x, big)).abs().max() < 1e-3
+    # non-finite flow (never produced by the path itself): ATen multiplies its zero-masked taps by NaN weights and writes NaN;
+    # the kernel deliberately writes 0 there (no tap is in range) so that one bad pixel cannot blank a canvas downstream --
+    # everywhere else the two agree
+    bad = fij.clone()
+    bad[0, 0, 5, 7], bad[1, 1, 9, 3], bad[0, 1, 20, 20] = float("nan"), float("inf"), -float("inf")
+    ob, rb = ops.flow_warp(dev(x), dev(bad)).cpu(), geom.warp(x, bad)
+    nanpos = ~torch.isfinite(rb)
+    assert torch.isfinite(ob).all() and nanpos.sum() == 3 * x.shape[1] and (ob[nanpos] == 0).all()
+    assert (ob[~nanpos] - rb[~nanpos]).abs().max() < 1e-3
     r = ops.resize_bilinear(dev(fij), 60, 100, True, div=(64 / 100.0, 48 / 60.0))
     assert (r.cpu() - T(golden_ops["resize_flow_out"])).abs().max() < 1e-5
     rin = T(golden_ops["resize512_in"])

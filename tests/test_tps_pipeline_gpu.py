@@ -208,3 +208,42 @@ def test_mix_stage_kernels_bit_exact():
     bl = ops.blend_pair(o1.cuda(), m1.cuda(), tps.cuda(), tm.cuda()).cpu()
     rb = torch.nan_to_num(((o1 * m1 + tps * tm) / (m1 + tm)).clip(0, 255), nan=0.0).to(torch.uint8)
     assert torch.equal(bl, rb)
+
+
+def test_opencv_branch_quantisation_and_points_vs_oracle(tp):
+    """tps_method='opencv' as the reference's own Python feeds it (opencv_tps.py:59-68, utils.py:10): image and mask truncated to
+    uint8 BEFORE the warp, result rounded / saturated, scales unused -- against the oracle restatement (fp64).  cv2's fixed-point
+    remap and its spline fit themselves stay unpinned (OpenCV is not importable)."""
+    case = otp.synthetic_case(9, 120, 160, -9, -7, 140, 180)
+    H_warp, H_mask = case["H_warp"], case["H_warp_mask"].clone()
+    H_mask[:, :, 40:44] = 0.7                                  # a fractional (bilinear-edge) mask strip: truncates to 0
+    g = torch.Generator().manual_seed(4)
+    src = torch.stack([torch.randint(10, 170, (1, 30), generator=g), torch.randint(10, 130, (1, 30), generator=g)], -1).float()
+    src = torch.cat([src, src[:, :3]], 1)                      # three coincident sites, as advanced_uniform_multi can produce
+    dst = src + torch.randint(-3, 4, src.shape, generator=g).float()
+    dst[:, -3:] = dst[:, :3]
+    ref = otp.warp_by_tps_opencv_like(H_warp, H_mask, src, dst)
+    got = tp.warp_by_tps(H_warp.cuda(), H_mask.cuda(), src, dst, 140, 180, "opencv", 3.0, 5.0).cpu()      # scales must be ignored
+    assert torch.equal(got, got.round()) and got.min() >= 0 and got.max() <= 255          # uint8-valued
+    d = (got - ref).abs()
+    mflips = int((got[:, 3:] != ref[:, 3:]).sum())
+    print(f"[opencv-like branch] |d| max {d.max():.0f}, fraction of values that differ {(d > 0).float().mean():.2e}, mask flips {mflips}")
+    check("opencv_like_differs_frac", (d > 0).float().mean(), 3e-3)         # fp32 spline evaluation vs fp64: a rounding tie now and then
+    check("opencv_like_max_levels", d.max(), 1.0, inclusive=True)
+    assert (got[:, 3:, 40:44] == 0).all() or (got[:, 3:] <= 1).all()
+
+
+def test_singular_tps_is_detected_not_nan(tp):
+    """coincident sites (kornia back-end: torch.linalg.solve raises in the reference) and collinear sites: the solve reports it,
+    the pipeline leaves the homography warp unchanged instead of writing NaN over the canvas."""
+    import stitch_amd
+    ops = stitch_amd.ops
+    img = torch.rand(1, 4, 64, 80).cuda() * 255
+    pts = torch.tensor([[10.0, 10.0], [30.0, 12.0], [20.0, 40.0], [10.0, 10.0]])
+    with pytest.raises(ops.SingularTPSError):
+        ops.tps2_solve((pts / 80).cuda(), (pts / 80).cuda(), (pts / 80).cuda(), mode=0)
+    line = torch.tensor([[5.0, 5.0], [10.0, 10.0], [20.0, 20.0], [40.0, 40.0]])
+    with pytest.raises(ops.SingularTPSError):
+        ops.tps2_solve(line.cuda(), line.cuda(), (line + 1).cuda(), mode=1)
+    out = tp.warp_by_tps(img[:, :3], img[:, 3:], pts[None], pts[None] + 1, 64, 80, "kornia", 1.0, 1.0)
+    assert torch.equal(out, img) and torch.isfinite(out).all()
