@@ -327,7 +327,13 @@ def test_dlt_and_mat3(ops, golden_ops):
     src, dst = T(golden_ops["dlt_src"]), T(golden_ops["dlt_dst"])
     H = torch.empty(5, 3, 3, device="cuda")
     ops.dlt4(dev(src[0]), dev(dst - src), H, 5, 1.0, 1.0, 1.0)
-    assert torch.equal(H.cpu(), T(golden_ops["dlt_H"]))
+    gH = T(golden_ops["dlt_H"])
+    # two bars: within rounding of the golden on ANY host (the golden's bits come from the MKL / AVX dispatch of the machine that
+    # generated it: oracle/ref_harness/make_goldens.py) ...
+    assert (H.cpu() - gH).abs().max() <= 2e-6 * max(1.0, gH.abs().max().item())
+    # ... and bit for bit against THIS committed golden (generated in the build container, AVX-512 MKL code path), which is what
+    # the C oracle and the kernel restate operation for operation
+    assert torch.equal(H.cpu(), gH)
     ops.dlt4(dev(src[0]), dev(dst - src), H, 5, 1.0, 1.0, 8.0)
     assert torch.equal(H.cpu(), geom.dlt4(src / 8, dst / 8))
     gen = torch.Generator().manual_seed(11)
