@@ -30,7 +30,6 @@ from .homography import pack_conv
 # LayerNorm in front of a K = 128 Linear runs inside the row-streaming GEMM (ops.conv_gemm(ln_eps=...)): gamma / beta are
 # folded into the weights at pack time.  ST_FUSE_LN=0 keeps the separate LayerNorm kernel (A/B measurements).
 FUSE_LN = os.environ.get("ST_FUSE_LN", "1") != "0"
-_DEC_SPLITK = int(os.environ.get("ST_DEC_SPLITK", "0"))          # A/B probe (temporary)
 
 
 def _new(rows, cols, dev, zero=False):
@@ -479,9 +478,11 @@ class FlowFormer(ParamTree):
         hxA, hxB, corr = S["hxA"], S["hxB"], S["corr"]
         g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
         ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu")
-        ops.conv_gemm(S["cor1"], D["convc2"][0], S["corflo"][:, :192], geom=g3, bias=D["convc2"][1], act="relu", split_k=_DEC_SPLITK)
+        # convc2 / convf2 (384 / 128 tiles): no split-K -- with several pairs in flight the other streams fill the idle CUs, and the
+        # slab traffic + reducer launches cost more than they buy (A/B on one box: 78.7 -> 79.0 pairs/s; 69.0 -> 68.5 with one pair in flight)
+        ops.conv_gemm(S["cor1"], D["convc2"][0], S["corflo"][:, :192], geom=g3, bias=D["convc2"][1], act="relu", split_k=1)
         ops.flow_encode(coords1, D["convf1"][0], D["convf1"][1], S["flo1"], hxA[:, 254:256], B, H1, W1)      # :321, gru.py:251,254
-        ops.conv_gemm(S["flo1"], D["convf2"][0], S["corflo"][:, 192:], geom=g3, bias=D["convf2"][1], act="relu", split_k=_DEC_SPLITK)
+        ops.conv_gemm(S["flo1"], D["convf2"][0], S["corflo"][:, 192:], geom=g3, bias=D["convf2"][1], act="relu", split_k=1)
         ops.conv_gemm(S["corflo"], D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu")
         # GMA aggregate: v^T = Wv . mf^T, out = mf + gamma * attn @ v
         ops.gma_aggregate(attn, hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], hxA[:, 256:], B, N)
