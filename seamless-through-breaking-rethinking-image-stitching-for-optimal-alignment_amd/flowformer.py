@@ -208,7 +208,7 @@ class FlowFormer(ParamTree):
 
     # ================================================================== shared blocks
     @staticmethod
-    def _mlp(x, n2, fc1, fc2, eps, out=None, fc1_ln=None):
+    def _mlp(x, n2, fc1, fc2, eps, out=None, fc1_ln=None, extra_res=None):
         dev = x.device
         h = _new(x.shape[0], fc1[0].shape[0], dev)
         if fc1_ln is not None and FUSE_LN:
@@ -218,7 +218,10 @@ class FlowFormer(ParamTree):
             ops.layernorm(x, n2[0], n2[1], y, eps)
             ops.conv_gemm(y, fc1[0], h, bias=fc1[1], act="gelu")
         o = _new(x.shape[0], x.shape[1], dev) if out is None else out
-        ops.conv_gemm(h, fc2[0], o, bias=fc2[1], aux0=x)
+        if extra_res is None:
+            ops.conv_gemm(h, fc2[0], o, bias=fc2[1], aux0=x)
+        else:
+            ops.conv_gemm(h, fc2[0], o, bias=fc2[1], aux0=x, epi="add", aux1=extra_res)      # a second residual in the same epilogue
         return o
 
     # ------------------------------------------------------------------ Twins-SVT-L stages 1-2
@@ -351,7 +354,7 @@ class FlowFormer(ParamTree):
         ops.conv_gemm(h, L["f3"][0], o, bias=L["f3"][1], aux0=x)
         return o
 
-    def _vertical(self, V, x, ctx, B, H1, W1, nl):
+    def _vertical(self, V, x, ctx, B, H1, W1, nl, extra_res=None):
         """VerticalSelfAttentionLayer (encoder.py:121-125): Block(LSA ws7) -> Block(GSA sr4) with context
         (twins.py:253-304, 336-392, 787-790).  x rows are (b, pixel n, latent l) -> row (b*N + n)*nl + l."""
         dev = x.device
@@ -434,7 +437,7 @@ class FlowFormer(ParamTree):
                                 att[sl], (C, nl * C), nl, 8, N, Nk, 16, 16 ** -0.5)
         x3 = _new(R, C, dev)
         ops.conv_gemm(att, V["gproj"][0], x3, bias=V["gproj"][1], aux0=x2)
-        return self._mlp(x3, V["gn2"], V["gfc1"], V["gfc2"], 1e-5, fc1_ln=V["gfc1_ln"])
+        return self._mlp(x3, V["gn2"], V["gfc1"], V["gfc2"], 1e-5, fc1_ln=V["gfc1_ln"], extra_res=extra_res)
 
     def _cost_encoder(self, cost_maps, ctx, B, H1, W1):
         """CostPerceiverEncoder.forward (encoder.py:258-287) -> cost memory rows [B*N*8, 128]."""
@@ -446,10 +449,10 @@ class FlowFormer(ParamTree):
         nl = pk["latents"].shape[0]
         for i in range(HP["encoder_depth"]):
             x = self._latent_layer(pk["self"][i], x, M, False)
-            x = self._vertical(pk["vert"][i], x, ctx, B, H1, W1, nl)
-        # cost_encoder_res (encoder.py:281-282) adds the short-cut; the only consumer of the memory is the
-        # decoder's linear k/v projection, so the sum is folded there: kv(x + s) = kv(x) + kv(s).
-        return x, short
+            # cost_encoder_res (encoder.py:281-282) adds the short-cut to the output of the last layer: a second residual operand
+            # in that layer's final GEMM epilogue (no add pass, one k/v projection in the decoder)
+            x = self._vertical(pk["vert"][i], x, ctx, B, H1, W1, nl, extra_res=short if i == HP["encoder_depth"] - 1 else None)
+        return x, None
 
     # ------------------------------------------------------------------ decoder
     def _gru_tables(self, inp, B, H1, W1):
@@ -517,10 +520,13 @@ class FlowFormer(ParamTree):
         ops.gma_attention(inp, D["qk"], qk, attn, B, N)
         # k, v of the cost-memory cross attention, once (decoder.py:68-70); memory = x + short_cut (linear -> two GEMMs)
         ca = D["ca"]
-        kv0 = _new(R * nl, 128, dev)
-        ops.conv_gemm(mem_short, ca["kv"][0], kv0, bias=ca["kv"][1])
         kv = _new(R * nl, 128, dev)
-        ops.conv_gemm(mem, ca["kv"][0], kv, aux0=kv0)
+        if mem_short is None:
+            ops.conv_gemm(mem, ca["kv"][0], kv, bias=ca["kv"][1])
+        else:                                                  # memory given as two addends: kv(x + s) = kv(x) + kv(s)
+            kv0 = _new(R * nl, 128, dev)
+            ops.conv_gemm(mem_short, ca["kv"][0], kv0, bias=ca["kv"][1])
+            ops.conv_gemm(mem, ca["kv"][0], kv, aux0=kv0)
         coords1 = _new(R, 2, dev)
         ops.coords_grid(coords1, B, H1, W1)
         for it in range(iters):

@@ -72,7 +72,7 @@ def main():
     cm32 = nets.corr_volume(e32["feat_s"], e32["feat_t"]).reshape(B * N, N)
     cm64 = nets.corr_volume(e64["feat_s"], e64["feat_t"]).reshape(B * N, N)
     row("cost volume", e_h["cost_maps"], cm32, cm64)
-    mem_h = (e_h["mem"] + e_h["short"]).reshape(B * N, 8, 128)
+    mem_h = (e_h["mem"] if e_h["short"] is None else e_h["mem"] + e_h["short"]).reshape(B * N, 8, 128)      # (the short-cut is added in the last layer's epilogue now)
     row("cost memory (encoder out)", mem_h, e32["cost_memory"], e64["cost_memory"])
     c0 = nets.coords_grid(B, H1, W1)
     acc32 = torch.zeros(B, 2, H1, W1)
