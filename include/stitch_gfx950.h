@@ -82,13 +82,41 @@ int st_set_gemm_observer(void* callback, void* user);
 
 /* Profiling aid: the launch plan the library chose for the calling thread's most recent st_conv_gemm:
  *   plan4[0] kernel family (0 skinny_gemm, 1 narrow_conv, 2 conv_gemm_kernel [register-staged], 3 conv_gemm_dma_kernel,
- *            4 rowstream_gemm_kernel)
+ *            4 rowstream_gemm_kernel, 5 rowchain128_kernel [st_linear_chain128, reported to the observer as M x 128L x 128])
  *   plan4[1] tile_cfg actually used, plan4[2] split_k actually used, plan4[3] 1 = persistent M walk.
  * Used by tools/gemm_shapes_csv.py to label every launch of a step (profiles/r2_gemm_shapes.csv). */
 int st_gemm_last_plan(int32_t* plan4);
 
 /* sizeof(st_gemm_desc) as compiled into the library (binding self-check; returns the size). */
 int st_abi_gemm_desc_size(void);
+
+/* A chain of up to 3 Linear(128 -> 128) layers over the rows of a matrix, evaluated without the intermediate activations
+ * leaving the CU (the tail of the latent layers: `proj + residual -> LayerNorm -> ffn.0 + GELU -> ffn.3 + residual`,
+ * crossattentionlayer.py:46-56, encoder.py:163-172):
+ *   x_0 = a;   x_{l+1} = act_l( LN_l(x_l) . w_l^T + bias_l ) + residual_l ;   out = x_nlayers
+ * LN_l (ln = 1): layer norm of the row WITHOUT affine (the caller folds gamma / beta into w_l / bias_l);
+ * residual_l: res = 0 none, 1 = rows of the global matrix res_ptr (row stride ld_res), 2 = x_{res_layer} (an earlier
+ * layer's input before its LN).  w_l [128,128] row-major contiguous, bias_l [128].  Same k pairing and summation order per
+ * layer as st_conv_gemm (bit-identical to the unfused chain).                                                          */
+typedef struct st_chain_layer {
+    const float* w;
+    const float* bias;
+    const float* res_ptr;
+    int32_t ld_res;
+    int32_t act;           /* 0 none, 1 relu, 2 gelu                                                                      */
+    int32_t ln;
+    float ln_eps;
+    int32_t res;
+    int32_t res_layer;
+} st_chain_layer;
+typedef struct st_chain_desc {
+    const float* a;        /* [M, lda], 128 columns used                                                                  */
+    float* out;            /* [M, ldo]                                                                                    */
+    int32_t lda, ldo, M, nlayers;
+    st_chain_layer layer[3];
+} st_chain_desc;
+int st_linear_chain128(const st_chain_desc* desc, void* stream);
+int st_abi_chain_desc_size(void);
 
 /* All-pairs correlation volume, MemoryEncoder.corr (encoder.py:359-369):
  *   f1, f2 [B, N, C] channels-last features -> vol [B, N1, N2] = f1 . f2^T (no scaling). */

@@ -32,6 +32,18 @@ class GemmDesc(C.Structure):
     )
 
 
+class ChainLayer(C.Structure):
+    """Mirror of ``st_chain_layer``."""
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("res_ptr", C.c_void_p), ("ld_res", C.c_int32), ("act", C.c_int32),
+                ("ln", C.c_int32), ("ln_eps", C.c_float), ("res", C.c_int32), ("res_layer", C.c_int32)]
+
+
+class ChainDesc(C.Structure):
+    """Mirror of ``st_chain_desc``."""
+    _fields_ = [("a", C.c_void_p), ("out", C.c_void_p), ("lda", C.c_int32), ("ldo", C.c_int32), ("M", C.c_int32), ("nlayers", C.c_int32),
+                ("layer", ChainLayer * 3)]
+
+
 def declared_functions(header=HEADER):
     """{name: [ctypes argtypes]} for every ``int st_*(...)`` declaration in the header."""
     src = open(header).read()

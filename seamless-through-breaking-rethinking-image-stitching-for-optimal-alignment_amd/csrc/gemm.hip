@@ -20,9 +20,16 @@
 // FlowHomoAdpater path, e.g. core/FlowFormer/PerCostFormer3/encoder.py:359-369 (all-pairs corr),
 // gru.py:44-59 (SepConvGRU), core/UDIS2/Homography/network.py:103-137 (ResNet-50 + regressor).
 #include "common.h"
+#include <string.h>
 #include "../../include/stitch_gfx950.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// optional profiling observer (st_set_gemm_observer) and the launch plan of the calling thread's last launch (st_gemm_last_plan)
+typedef void (*st_gemm_observer_fn)(const st_gemm_desc*, void* stream, int32_t phase, void* user);
+static st_gemm_observer_fn g_observer = nullptr;
+static void* g_observer_user = nullptr;
+static thread_local int32_t g_last_plan[4] = {-1, 0, 0, 0};
 
 #define BK 32
 #define LDS_LD (BK + 4)
@@ -953,6 +960,202 @@ __global__ __launch_bounds__(512) void rowstream_gemm_kernel(const st_gemm_desc 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row chain: up to three Linear(128 -> 128) layers applied to 32-row blocks that never leave the CU (st_linear_chain128).
+// Built on the row-streaming kernel: a wave keeps its block in registers in the A-operand layout (lane (li, lh) holds
+// k = 8j + 4lh + t of row li); a layer is four 32-column chunks of 64 MFMAs; each chunk's result (C layout) takes bias and
+// activation, crosses a 4.5-KiB per-wave LDS slab and comes back as four more float4 of the NEXT layer's A operand.
+// LayerNorm and the residual adds happen in that layout, in registers.  Weights stream through a 3-stage LDS ring of
+// 32-row chunks shared by the waves of the workgroup (LDS DMA, XOR-swizzled 128-B-row image as in conv_gemm_dma_kernel; one
+// barrier per chunk, the chunk two steps ahead in flight).  Per layer the k pairing and summation order are those of the
+// other kernels: bit-identical.
+#define RC_LDS 36
+#define RC_NW 4                                                  // waves per workgroup, two workgroups per CU (starting half of them half a
+                                                                 // step late so that co-resident waves run out of phase: measured neutral)
+__global__ __launch_bounds__(256, 2) void rowchain128_kernel(const st_chain_desc d) {
+    constexpr int NJ = 16, NW = RC_NW;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    float* ring = smem;                                        // [3][32 rows][128 k] unpadded, 16-B slots XOR-swizzled by (row & 15)
+    float* slab_all = smem + 3 * 32 * 128;                     // [NW][32][RC_LDS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    float* slab = slab_all + wave * 32 * RC_LDS;
+    const int nblk = (d.M + 31) >> 5;
+    const int G = (int)gridDim.x;
+    const int blk0 = (int)blockIdx.x * NW;
+    const int rounds = blk0 < nblk ? (nblk - blk0 + G * NW - 1) / (G * NW) : 0;
+    const int L = d.nlayers, steps = 4 * L, total = rounds * steps;
+    if (total == 0) return;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+
+    // weight chunk q of the (round-periodic) sequence = rows [32c, 32c + 32) of layer (q % steps) / 4 -> ring stage q % 3, by LDS DMA:
+    // 16 pieces of 1 KiB (two rows each), 16 / NW per wave; lane l of a piece writes slot l & 31 of row 2p + (l >> 5), which holds
+    // k-chunk slot ^ (row & 15) (the swizzle is applied on the source side)
+    auto dma_chunk = [&](int q) {
+        const int qq = q % steps, l = qq >> 2, c = qq & 3;
+        const i32x4 rs = make_rsrc(d.layer[l].w, 128 * 128 * 4);
+#pragma unroll
+        for (int u = 0; u < 16 / NW; ++u) {
+            const int p = wave * (16 / NW) + u, r = 2 * p + (lane >> 5);
+            const unsigned voff = (unsigned)(((c * 32 + r) * 128 + (((lane & 31) ^ (r & 15)) << 2)) * 4);
+            lds_dma16(rs, lds0 + (unsigned)(((q % 3) * 32 * 128 + p * 256) * 4), voff, 0u);
+        }
+    };
+    dma_chunk(0);
+    if (total > 1) dma_chunk(1);
+    // fragment slot offsets (floats) of this lane: 16-B slot (2j + lh) ^ (li & 15) -- the XOR touches the low four bits only
+    int foff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) foff[j] = (((2 * j + lh) ^ (li & 15)) << 2);
+
+    float4 a[NJ], an[NJ], sv[NJ];
+    int q = 0;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int blk = blk0 + wave + rd * G * NW;
+        const bool active = blk < nblk;                         // wave-uniform; idle waves still load weights and meet the barriers
+        const int row = blk * 32 + li;
+        const bool rok = active && row < d.M;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                a[j] = rok ? *reinterpret_cast<const float4*>(d.a + (size_t)row * d.lda + 8 * j + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int l = 0; l < L; ++l) {
+            const st_chain_layer& Ly = d.layer[l];
+            if (active) {
+                // a later layer adds THIS layer's input (before its LN) as residual: keep a copy
+                bool keep = false;
+                for (int m = l; m < L; ++m) keep = keep || (d.layer[m].res == 2 && d.layer[m].res_layer == l);
+                if (keep) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) sv[j] = a[j];
+                }
+                if (Ly.ln) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) s += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+                    s += __shfl_xor(s, 32, 64);
+                    const float mean = s * (1.0f / 128.0f);
+                    float v = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        a[j].x -= mean; a[j].y -= mean; a[j].z -= mean; a[j].w -= mean;
+                        v += (a[j].x * a[j].x + a[j].y * a[j].y) + (a[j].z * a[j].z + a[j].w * a[j].w);
+                    }
+                    v += __shfl_xor(v, 32, 64);
+                    const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + Ly.ln_eps);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { a[j].x *= rstd; a[j].y *= rstd; a[j].z *= rstd; a[j].w *= rstd; }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c, ++q) {
+                // chunk q (DMA issued two steps ago, waited for at the end of the previous step) is in the ring once every wave's
+                // pieces have landed; everyone is past chunk q - 1, whose stage chunk q + 2 may now overwrite
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (q + 2 < total) dma_chunk(q + 2);
+                if (active) {
+                    const float* wb = ring + (q % 3) * 32 * 128 + li * 128;
+                    const float bv = Ly.bias ? Ly.bias[c * 32 + li] : 0.f;
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    float4 b = *reinterpret_cast<const float4*>(wb + foff[0]);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int jn = j + 1 < NJ ? j + 1 : j;
+                        const float4 bn = *reinterpret_cast<const float4*>(wb + foff[jn & 7] + (jn >> 3) * 64);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b.w, acc, 0, 0, 0);
+                        b = bn;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // bias + activation in the C layout (row (r&3) + 8(r>>2) + 4lh, column li), then through the slab
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
+                    if (Ly.act == ST_ACT_GELU) {                 // wave-uniform, outside the register loop (none / relu / gelu only)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = st_gelu(v[r]);
+                    } else if (Ly.act == ST_ACT_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slab[(ST_EPI_ROW(r) + 4 * lh) * RC_LDS + li] = v[r];
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) an[4 * c + jj] = *reinterpret_cast<const float4*>(slab + li * RC_LDS + 8 * jj + 4 * lh);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (active) {
+                if (Ly.res == 1) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const float4 x = rok ? *reinterpret_cast<const float4*>(Ly.res_ptr + (size_t)row * Ly.ld_res + 8 * j + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        an[j].x += x.x; an[j].y += x.y; an[j].z += x.z; an[j].w += x.w;
+                    }
+                } else if (Ly.res == 2) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { an[j].x += sv[j].x; an[j].y += sv[j].y; an[j].z += sv[j].z; an[j].w += sv[j].w; }
+                }
+                if (l == L - 1) {
+                    if (rok) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(d.out + (size_t)row * d.ldo + 8 * j + 4 * lh) = an[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) a[j] = an[j];
+                }
+            }
+        }
+    }
+}
+
+extern "C" int st_abi_chain_desc_size(void) { return (int)sizeof(st_chain_desc); }
+
+extern "C" int st_linear_chain128(const st_chain_desc* desc, void* stream) {
+    if (!desc) return ST_EINVAL;
+    const st_chain_desc& d = *desc;
+    if (!d.a || !d.out || d.M <= 0 || d.nlayers < 1 || d.nlayers > 3 || d.lda < 128 || d.ldo < 128 || (d.lda & 3) || (d.ldo & 3) ||
+        ((uintptr_t)d.a & 15) || ((uintptr_t)d.out & 15) || (int64_t)d.M * (d.lda > d.ldo ? d.lda : d.ldo) >= ((int64_t)1 << 40))
+        return ST_EINVAL;
+    for (int l = 0; l < d.nlayers; ++l) {
+        const st_chain_layer& y = d.layer[l];
+        if (!y.w || ((uintptr_t)y.w & 15) || y.act < 0 || y.act > ST_ACT_GELU || y.res < 0 || y.res > 2) return ST_EINVAL;
+        if (y.res == 1 && (!y.res_ptr || y.ld_res < 128 || (y.ld_res & 3) || ((uintptr_t)y.res_ptr & 15))) return ST_EINVAL;
+        if (y.res == 2 && (y.res_layer < 0 || y.res_layer > l)) return ST_EINVAL;
+    }
+    const int nblk = (d.M + 31) / 32;
+    int G = (nblk + RC_NW - 1) / RC_NW;
+    if (G > 512) G = 512;                                       // two workgroups per CU
+    const size_t lds = (size_t)(3 * 32 * 128 + RC_NW * 32 * RC_LDS) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)rowchain128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the profiling observer sees the chain as one launch of the family: M x (128 * nlayers) x 128 (its FLOPs; the A + W + C byte
+    // formula of the tools then counts the intermediate activations that this kernel does NOT move)
+    st_gemm_observer_fn obs = g_observer;
+    st_gemm_desc od;
+    if (obs) {
+        memset(&od, 0, sizeof(od));
+        od.a = d.a; od.c = d.out; od.w = d.layer[0].w;
+        od.M = d.M; od.N = 128 * d.nlayers; od.K = 128; od.H = 1; od.W = d.M; od.Cin = 128; od.ldx = d.lda; od.ldc = d.ldo; od.ldw = 128;
+        od.kh = od.kw = od.sh = od.sw = 1; od.Ho = 1; od.Wo = d.M; od.batch = 1; od.alpha = 1.f;
+        obs(&od, stream, 0, g_observer_user);
+    }
+    g_last_plan[0] = 5; g_last_plan[1] = 30; g_last_plan[2] = 1; g_last_plan[3] = 1;
+    hipLaunchKernelGGL(rowchain128_kernel, dim3(G), dim3(64 * RC_NW), lds, (hipStream_t)stream, d);
+    if (obs) obs(&od, stream, 1, g_observer_user);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 // split-K tail: sum the K-slice slabs [split][M][N] in slice order (deterministic) + epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const st_gemm_desc d) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1114,7 +1317,6 @@ __global__ __launch_bounds__(256) void narrow_conv3x3_kernel(const st_gemm_desc 
     }
 }
 
-static thread_local int32_t g_last_plan[4] = {-1, 0, 0, 0};
 
 template <int WARPS_M, int WARPS_N, int TM, int TN>
 static int launch_cfg(const st_gemm_desc& d, bool vec, hipStream_t s) {
@@ -1388,9 +1590,6 @@ extern "C" int st_abi_gemm_desc_size(void) { return (int)sizeof(st_gemm_desc); }
 // Optional profiling observer (bench.py's live roofline): called on the launching thread before (phase 0)
 // and after (phase 1) the kernels of every st_conv_gemm are enqueued -- including the launches made by the
 // operator-level entry points -- so the caller can record HIP events on `stream`.  NULL (default) = off.
-typedef void (*st_gemm_observer_fn)(const st_gemm_desc*, void* stream, int32_t phase, void* user);
-static st_gemm_observer_fn g_observer = nullptr;
-static void* g_observer_user = nullptr;
 
 extern "C" int st_set_gemm_observer(void* callback, void* user) {
     g_observer = (st_gemm_observer_fn)callback;

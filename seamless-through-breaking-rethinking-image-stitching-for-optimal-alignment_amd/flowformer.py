@@ -30,6 +30,7 @@ from .homography import pack_conv
 # LayerNorm in front of a K = 128 Linear runs inside the row-streaming GEMM (ops.conv_gemm(ln_eps=...)): gamma / beta are
 # folded into the weights at pack time.  ST_FUSE_LN=0 keeps the separate LayerNorm kernel (A/B measurements).
 FUSE_LN = os.environ.get("ST_FUSE_LN", "1") != "0"
+FUSE_CHAIN = os.environ.get("ST_FUSE_CHAIN", "1") != "0"        # the latent layers' 128-wide tails as one st_linear_chain128 launch
 
 
 def _new(rows, cols, dev, zero=False):
@@ -336,6 +337,13 @@ class FlowFormer(ParamTree):
             att = _new(M * nl, 128, dev)
             ops.attention_small(qkv[:, :128], (nl * 384, 384), qkv[:, 128:256], (nl * 384, 384), qkv[:, 256:], (nl * 384, 384),
                                 att, (nl * 128, 128), M, 8, nl, nl, 16, 16 ** -0.5)
+            if FUSE_CHAIN:
+                # proj + residual -> LayerNorm -> ffn.0 + GELU -> ffn.3 + residual in ONE launch: x1 and the hidden activation
+                # never leave the CU (encoder.py:163-172)
+                o = _new(M * nl, 128, dev)
+                return ops.linear_chain128(att, o, [dict(w=L["proj"][0], bias=L["proj"][1], res=x),
+                                                    dict(w=L["f0_ln"][0], bias=L["f0_ln"][1], act="gelu", ln_eps=1e-5),
+                                                    dict(w=L["f3"][0], bias=L["f3"][1], res=1)])
             x1 = _new(M * nl, 128, dev)
             ops.conv_gemm(att, L["proj"][0], x1, bias=L["proj"][1], aux0=x)
         return self._mlp_plain(x1, L)
@@ -343,6 +351,9 @@ class FlowFormer(ParamTree):
     @staticmethod
     def _mlp_plain(x, L):
         dev = x.device
+        if FUSE_CHAIN:                                          # LayerNorm -> ffn.0 + GELU -> ffn.3 + residual, one launch
+            return ops.linear_chain128(x, _new(x.shape[0], x.shape[1], dev),
+                                       [dict(w=L["f0_ln"][0], bias=L["f0_ln"][1], act="gelu", ln_eps=1e-5), dict(w=L["f3"][0], bias=L["f3"][1], res=0)])
         h = _new(x.shape[0], L["f0"][0].shape[0], dev)
         if FUSE_LN:
             ops.conv_gemm(x, L["f0_ln"][0], h, bias=L["f0_ln"][1], act="gelu", ln_eps=1e-5)

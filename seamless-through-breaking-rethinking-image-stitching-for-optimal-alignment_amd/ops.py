@@ -6,13 +6,14 @@ import ctypes as C
 
 import torch
 
-from ._lib import GemmDesc, check, lib
+from ._lib import ChainDesc, GemmDesc, check, lib
 from ._lib import StitchError as StitchErrorBase
 
 ACT = dict(none=0, relu=1, gelu=2, sigmoid=3, tanh=4)
 EPI = dict(store=0, add=1, mul=2, gru=3, axpy=4, zr=5)
 
 assert lib.st_abi_gemm_desc_size() == C.sizeof(GemmDesc), "st_gemm_desc ABI mismatch between header and binding"
+assert lib.st_abi_chain_desc_size() == C.sizeof(ChainDesc), "st_chain_desc ABI mismatch between header and binding"
 
 
 def _stream():
@@ -139,6 +140,30 @@ def fold_layernorm(gamma, beta, w, bias=None):
     if bias is not None:
         bf = bf + bias.detach().double().cpu()
     return wf, bf.float().contiguous().to(dev)
+
+
+def linear_chain128(a, out, layers):
+    """out = chain of up to 3 Linear(128 -> 128) layers over the rows of ``a`` without intermediate round trips (st_linear_chain128).
+    layers: dicts with w [128,128], bias [128] or None, act (name), ln_eps (None = no LayerNorm of the layer's input; the affine is
+    folded into w / bias: ``fold_layernorm``), res: None | a [M, >=128] tensor added to the layer's output | int l = the input of layer l."""
+    d = ChainDesc()
+    d.a, d.out, d.lda, d.ldo, d.M, d.nlayers = a.data_ptr(), out.data_ptr(), _ld(a), _ld(out), a.shape[0], len(layers)
+    for i, y in enumerate(layers):
+        ly = d.layer[i]
+        w = y["w"]
+        assert w.shape == (128, 128) and w.is_contiguous()
+        ly.w, ly.bias = w.data_ptr(), (y["bias"].data_ptr() if y.get("bias") is not None else None)
+        ly.act = ACT[y.get("act", "none")]
+        ly.ln, ly.ln_eps = (1, float(y["ln_eps"])) if y.get("ln_eps") is not None else (0, 0.0)
+        r = y.get("res")
+        if r is None:
+            ly.res = 0
+        elif isinstance(r, int):
+            ly.res, ly.res_layer = 2, r
+        else:
+            ly.res, ly.res_ptr, ly.ld_res = 1, r.data_ptr(), _ld(r)
+    check(lib.st_linear_chain128(C.byref(d), _stream()), "st_linear_chain128")
+    return out
 
 
 def corr_volume(f1, f2, out):

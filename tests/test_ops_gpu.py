@@ -751,3 +751,36 @@ def test_flow_encode(ops, B, H, W):
     assert (out[:, 4:132].cpu().double() - ref).abs().max() < 2e-5
     assert (out[:, :4] == 7.0).all() and (out[:, 132:] == 7.0).all()
     assert (wide[:, 5:7].cpu() - flow.permute(0, 2, 3, 1).reshape(-1, 2)).abs().max() < 1e-5 and (wide[:, :5] == 7.0).all() and (wide[:, 7] == 7.0).all()
+
+
+@pytest.mark.parametrize("M", [65536, 4100, 33])
+def test_linear_chain128(ops, M):
+    """st_linear_chain128: proj + residual -> LayerNorm -> ffn.0 + GELU -> ffn.3 + residual (crossattentionlayer.py:46-56,
+    encoder.py:163-172) in one launch, against fp64 torch and BIT-IDENTICAL to the unfused chain of st_conv_gemm launches."""
+    gg = g(5)
+    att, x = torch.randn(M, 128, generator=gg), torch.randn(M, 128, generator=gg)
+    lin = lambda: (torch.randn(128, 128, generator=gg) / 128 ** 0.5, torch.randn(128, generator=gg) * 0.1)      # noqa: E731
+    (wp, bp), (w0, b0), (w3, b3) = lin(), lin(), lin()
+    gam, bet = torch.rand(128, generator=gg) + 0.5, torch.randn(128, generator=gg) * 0.1
+    x1 = F.linear(att.double(), wp.double(), bp.double()) + x.double()
+    h = F.gelu(F.linear(F.layer_norm(x1, (128,), gam.double(), bet.double(), 1e-5), w0.double(), b0.double()))
+    ref = F.linear(h, w3.double(), b3.double()) + x1
+    w0f, b0f = ops.fold_layernorm(dev(gam), dev(bet), dev(w0), dev(b0))
+    attw = torch.zeros(M, 136, device="cuda")
+    attw[:, 4:132] = att.cuda()
+    out = torch.full((M, 136), 7.0, device="cuda")
+    ops.linear_chain128(attw[:, 4:132], out[:, 4:132], [dict(w=dev(wp), bias=dev(bp), res=dev(x)),
+                                                         dict(w=w0f, bias=b0f, act="gelu", ln_eps=1e-5),
+                                                         dict(w=dev(w3), bias=dev(b3), res=1)])
+    assert (out[:, 4:132].cpu().double() - ref).abs().max() < 5e-5
+    assert (out[:, :4] == 7.0).all() and (out[:, 132:] == 7.0).all()
+    # the unfused chain: three launches
+    x1u, hu, ou = (torch.empty(M, 128, device="cuda") for _ in range(3))
+    ops.conv_gemm(att.cuda(), dev(wp), x1u, bias=dev(bp), aux0=dev(x))
+    ops.conv_gemm(x1u, w0f, hu, bias=b0f, act="gelu", ln_eps=1e-5)
+    ops.conv_gemm(hu, dev(w3), ou, bias=dev(b3), aux0=x1u)
+    assert torch.equal(out[:, 4:132], ou)
+    # two-layer form (LayerNorm -> ffn.0 -> ffn.3 + input)
+    o2 = torch.empty(M, 128, device="cuda")
+    ops.linear_chain128(x1u, o2, [dict(w=w0f, bias=b0f, act="gelu", ln_eps=1e-5), dict(w=dev(w3), bias=dev(b3), res=0)])
+    assert torch.equal(o2, ou)
