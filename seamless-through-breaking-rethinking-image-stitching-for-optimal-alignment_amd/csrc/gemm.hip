@@ -1504,7 +1504,8 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         if (d.a_ln && !(rs_ok && (d.tile_cfg == 0 || d.tile_cfg == 20))) return ST_EINVAL;
         if (rs_ok && (rs_want || d.a_ln)) {
             g_last_plan[0] = 4; g_last_plan[1] = 20; g_last_plan[2] = 1; g_last_plan[3] = 1;
-            return d.K == 64 ? launch_rowstream<2>(d, 8, s) : launch_rowstream<4>(d, 8, s);
+            return d.K == 64 ? launch_rowstream<2>(d, 8, s) : launch_rowstream<4>(d, 8, s);      // 8-chunk slices (4-chunk ones, which would let a
+            //                                                       64-KiB GEMM workgroup co-reside, measured 0.3 % slower with 3 pairs in flight)
         }
         if (d.tile_cfg >= 20) return ST_EINVAL;
     }
