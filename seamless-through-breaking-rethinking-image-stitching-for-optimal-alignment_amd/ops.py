@@ -77,8 +77,10 @@ class workspace_scope:
 
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
               epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, dil=(1, 1), M=None, tile=0, split_k=0, out2=None,
-              ln_eps=None):
+              ln_eps=None, a2=None, a2_channels=0):
     """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
+
+    a2 / a2_channels: input channels below a2_channels are read from ``a2`` (same shape and row stride as x) instead of x.
 
     ln_eps: the rows of x are layer-normalised (no affine: fold gamma / beta into w / bias, ``fold_layernorm``) inside
     the kernel before the product (row-streaming kernel only: plain matrix, K = 64 / 128).
@@ -120,6 +122,9 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     d.split_k = split_k
     if ln_eps is not None:
         d.a_ln, d.a_ln_eps = 1, float(ln_eps)
+    if a2 is not None:
+        assert a2.shape == x.shape and _ld(a2) == _ld(x), "second A source: same geometry and row stride as x"
+        d.a2, d.a2_channels = a2.data_ptr(), int(a2_channels)
     if out2 is not None:
         d.c2, d.ldc2 = out2.data_ptr(), _ld(out2)
     if batch <= 1 and split_k != 1:

@@ -198,6 +198,10 @@ def test_sine_pe(ops):
     o2 = torch.ones(45, 192, device="cuda")
     ops.sine_pe(o2, 192, Wg=9, cscale=8.0, coff=4.0, accumulate=True)
     assert (o2.cpu() - (1 + nets.sine_pe(grid * 8 + 4, 192))).abs().max() < 3e-5
+    o4 = torch.full((45, 192), 5.0, device="cuda")                      # columns < 128 written, columns >= 128 accumulated
+    ops.sine_pe(o4, 192, Wg=9, cscale=8.0, coff=4.0, accumulate=128)
+    pe = nets.sine_pe(grid * 8 + 4, 192)
+    assert (o4[:, :128].cpu() - pe[:, :128]).abs().max() < 3e-5 and (o4[:, 128:].cpu() - (5 + pe[:, 128:])).abs().max() < 3e-5
     o3 = torch.empty(14 * 14, 128, device="cuda")
     ops.sine_pe(o3, 128, Wg=14, ws=7)
     gx = nets.coords_grid(1, 14, 14).view(1, 2, -1).permute(0, 2, 1)[0] % 7
@@ -784,3 +788,27 @@ def test_linear_chain128(ops, M):
     o2 = torch.empty(M, 128, device="cuda")
     ops.linear_chain128(x1u, o2, [dict(w=w0f, bias=b0f, act="gelu", ln_eps=1e-5), dict(w=dev(w3), bias=dev(b3), res=0)])
     assert torch.equal(o2, ou)
+
+
+@pytest.mark.parametrize("kh,kw,ph,pw", [(1, 5, 0, 2), (3, 3, 1, 1)])
+def test_gemm_second_a_source(ops, kh, kw, ph, pw):
+    """st_gemm_desc.a2: input channels < a2_channels come from a second buffer of the same geometry (SepConvGRU's q conv reads
+    [r*h | x] without x being copied, gru.py:50) -- identical to the conv over the concatenated buffer; rejected where the
+    LDS-DMA kernel cannot run."""
+    B, H, W, C, Co = 2, 24, 20, 384, 128
+    gg = g(9)
+    xa, xb = torch.randn(B * H * W, C, generator=gg), torch.randn(B * H * W, C, generator=gg)
+    w = torch.randn(Co, kh * kw * C, generator=gg) / (kh * kw * C) ** 0.5
+    cat = xa.clone()
+    cat[:, :128] = xb[:, :128]
+    geom = (B, H, W, kh, kw, 1, 1, ph, pw)
+    ref, out = torch.empty(B * H * W, Co, device="cuda"), torch.empty(B * H * W, Co, device="cuda")
+    ops.conv_gemm(dev(cat), dev(w), ref, geom=geom, act="tanh")
+    xbn = xb.clone()
+    xbn[:, 128:] = float("nan")                                  # the part of the second buffer that must never be read
+    ops.conv_gemm(dev(xa), dev(w), out, geom=geom, act="tanh", a2=dev(xbn), a2_channels=128)
+    assert torch.equal(out, ref)
+    with pytest.raises(Exception):
+        ops.conv_gemm(dev(xa), dev(w), out, geom=geom, a2=dev(xbn), a2_channels=100)         # not a whole number of 32-channel steps
+    with pytest.raises(Exception):
+        ops.conv_gemm(dev(xa), dev(w), out, geom=geom, a2=dev(xbn), a2_channels=128, tile=3)  # register-staged kernel: no second source
