@@ -117,3 +117,21 @@ def test_composition_checkpoint_key_set():
         net.load_state_dict(bad, strict=True)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 512, 512), torch.zeros(1, 3, 512, 512))      # CPU tensors: no fallback
+
+
+def test_fold_layernorm_is_exact_algebra():
+    """ops.fold_layernorm: Linear(LayerNorm(x)) == (x - mean) * rstd @ (W * gamma)^T + (b + W @ beta) -- the weight-only folding that
+    lets the GEMM normalise its A rows in registers (st_gemm_desc.a_ln); checked in fp64 on the host."""
+    import stitch_amd
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(50, 128, generator=g, dtype=torch.float64) * 3 + 1
+    gam, bet = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    w, b = torch.randn(96, 128, generator=g), torch.randn(96, generator=g)
+    wf, bf = stitch_amd.ops.fold_layernorm(gam, bet, w, b)
+    assert wf.dtype == torch.float32 and wf.shape == w.shape and bf.shape == b.shape
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (128,), gam.double(), bet.double(), 1e-5), w.double(), b.double())
+    xn = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    got = xn @ wf.double().t() + bf.double()
+    assert (got - ref).abs().max() < 5e-6                    # (the folded weights are rounded to fp32 once)
+    wf2, bf2 = stitch_amd.ops.fold_layernorm(gam, bet, w)    # no bias: b' = W @ beta
+    assert torch.equal(wf2, wf) and (bf2.double() - (w.double() @ bet.double())).abs().max() < 1e-6
