@@ -9,6 +9,13 @@ import ctypes as C
 import os
 import re
 
+# torch FIRST: it brings its own HIP runtime (torch/lib/libamdhip64.so, loaded with global symbol scope).  Loading
+# libstitch_gfx950.so before torch would bind its hip* calls to a SECOND runtime (/opt/rocm's libamdhip64.so.7 from its
+# DT_NEEDED entry): two HIP / HSA runtimes in one process, kernels launched through one on memory and streams owned by the other --
+# on the GPU box that ends in hipErrorNoDevice at the first launch.  With torch's runtime already global, the library's calls
+# resolve to it.
+import torch  # noqa: F401,E402
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstitch_gfx950.so")
 HEADER = os.path.join(HERE, "..", "include", "stitch_gfx950.h")
