@@ -73,6 +73,12 @@ typedef struct st_gemm_desc {
  *   twins.py:253-392,587-680 (q/k/v/proj/sr/MLP), core/UDIS2/Homography/network.py:18-46,103-137. */
 int st_conv_gemm(const st_gemm_desc* desc, void* stream);
 
+/* Two independent contractions in ONE launch: workgroups of both descriptors share the grid, so two mid-size convs that are
+ * ready together (BasicMotionEncoder's convc2 and convf2, gru.py:252-253) fill the chip without split-K slabs or a second
+ * launch.  Both must be LDS-DMA-kernel shapes (Cin % 32 == 0, K >= 128), batch <= 1, no split-K, no a_ln; results are
+ * bit-identical to two st_conv_gemm calls.                                                                            */
+int st_conv_gemm_pair(const st_gemm_desc* desc0, const st_gemm_desc* desc1, void* stream);
+
 /* Profiling observer, off by default: `callback` is a
  *   void (*)(const st_gemm_desc*, void* stream, int32_t phase, void* user)
  * invoked on the launching thread before (phase 0) and after (phase 1) every st_conv_gemm enqueues its kernels

@@ -545,7 +545,7 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
 // column tile with ONE continuous DMA ring, so the operand tiles of the next M tile stream in under the epilogue
 // of the current one (short-K GEMMs -- K = 128 has four K steps per tile -- are otherwise all load latency).
 template <int WM, int WN, int TM, int TN, int STAGES, bool PERSIST>
-__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d) {
+__device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const int block_id) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, ROWS = BM + BN;
     constexpr int PA = BM / 32, PB = BN / 32;      // 1-KiB pieces (8 rows x 128 B) per wave and K step
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
 
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
     const int nwg = PERSIST ? (int)gridDim.x : ntm * ntn;
-    int bid = blockIdx.x;
+    int bid = block_id;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -823,6 +823,24 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d
 #undef ST_GAP
 
     if (!PERSIST) gemm_epilogue_store<TM, TN>(d, C, acc, eop, m0, n0, wm, wn, li, lh, split, kz);
+}
+
+template <int WM, int WN, int TM, int TN, int STAGES, bool PERSIST>
+__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d) {
+    conv_gemm_dma_body<WM, WN, TM, TN, STAGES, PERSIST>(d, (int)blockIdx.x);
+}
+
+// Two independent contractions in ONE launch (st_conv_gemm_pair): workgroups [0, tiles0) run d[0], the rest d[1].  For pairs of
+// mid-size convs that are ready at the same time and each fill only part of the chip (BasicMotionEncoder's convc2: 384 tiles, and
+// convf2: 128 tiles, gru.py:252-253): together they give every CU two workgroups without split-K slabs or a second launch.
+struct st_gemm_pair_args {
+    st_gemm_desc d[2];
+    int32_t tiles0;
+};
+template <int WM, int WN, int TM, int TN, int STAGES>
+__global__ __launch_bounds__(256) void conv_gemm_dma_pair_kernel(const st_gemm_pair_args g) {
+    const bool second = (int)blockIdx.x >= g.tiles0;             // workgroup-uniform
+    conv_gemm_dma_body<WM, WN, TM, TN, STAGES, false>(second ? g.d[1] : g.d[0], second ? (int)blockIdx.x - g.tiles0 : (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1561,6 +1579,55 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         case 4: return launch_cfg<4, 1, 1, 1>(d, aligned, s);
         default: return ST_EINVAL;
     }
+}
+
+// Checks + buffer extents of a descriptor that must run on the plain (non-persistent, unsplit) 64x64 LDS-DMA kernel.
+static int pair_member_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
+    d = *desc;
+    if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
+    if (d.kh <= 0 || d.kw <= 0 || d.K != d.kh * d.kw * d.Cin || d.K < 128 || d.Cin % 32) return ST_EINVAL;
+    if (d.Ho <= 0 || d.Wo <= 0 || d.M % (d.Ho * d.Wo)) return ST_EINVAL;
+    if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
+    if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
+    if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
+    if (d.reserved0 != 0 || d.reserved1 != 0 || d.a_ln || d.batch > 1 || d.split_k > 1 || (d.tile_cfg != 0 && d.tile_cfg != 13)) return ST_EINVAL;
+    if (d.a2 && (d.a2_channels <= 0 || d.a2_channels % 32 || d.a2_channels > d.Cin || ((uintptr_t)d.a2 & 15))) return ST_EINVAL;
+    if (((uintptr_t)d.a & 15) || ((uintptr_t)d.w & 15) || (d.ldx & 3) || (d.ldw & 3)) return ST_EINVAL;
+    const bool plain_mat = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && (int64_t)d.H * d.W == d.M &&
+                           (int64_t)d.Ho * d.Wo == d.M;
+    const int64_t hw = plain_mat ? 1 : (int64_t)d.Ho * d.Wo, nimg = d.M / hw, img_rows = plain_mat ? 1 : (int64_t)d.H * d.W;
+    const int64_t ab = ((nimg * img_rows - 1) * d.ldx + d.Cin) * 4, wb = ((int64_t)(d.N - 1) * d.ldw + d.K) * 4;
+    int64_t ldmax = d.ldc > d.N ? d.ldc : d.N;
+    if (d.aux0 && d.ld_aux0 > ldmax) ldmax = d.ld_aux0;
+    if (d.aux1 && d.ld_aux1 > ldmax) ldmax = d.ld_aux1;
+    if (d.aux2 && d.ld_aux2 > ldmax) ldmax = d.ld_aux2;
+    if (d.c2 && d.ldc2 > ldmax) ldmax = d.ldc2;
+    if (wb >= (int64_t)ST_OOB || ab >= (int64_t)ST_OOB || ((int64_t)d.M + 256) * ldmax * 4 >= ((int64_t)1 << 31)) return ST_EINVAL;   // (no row chunking here)
+    d.a_bytes = (uint32_t)ab; d.w_bytes = (uint32_t)wb;
+    d.split_k = 1; d.batch = 1;
+    return ST_OK;
+}
+
+extern "C" int st_conv_gemm_pair(const st_gemm_desc* desc0, const st_gemm_desc* desc1, void* stream) {
+    if (!desc0 || !desc1) return ST_EINVAL;
+    st_gemm_pair_args g;
+    int rc = pair_member_prepare(desc0, g.d[0]);
+    if (rc) return rc;
+    rc = pair_member_prepare(desc1, g.d[1]);
+    if (rc) return rc;
+    auto tiles = [](const st_gemm_desc& d) { return ((d.M + 63) / 64) * ((d.N + 63) / 64); };
+    g.tiles0 = tiles(g.d[0]);
+    const int total = g.tiles0 + tiles(g.d[1]);
+    st_gemm_observer_fn obs = g_observer;
+    if (obs) { obs(desc0, stream, 0, g_observer_user); obs(desc0, stream, 1, g_observer_user); obs(desc1, stream, 0, g_observer_user); }
+    g_last_plan[0] = 3; g_last_plan[1] = 13; g_last_plan[2] = 1; g_last_plan[3] = 0;
+    auto k = conv_gemm_dma_pair_kernel<2, 2, 1, 1, 4>;
+    const size_t lds = (size_t)4 * (64 + 64) * 32 * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(total), dim3(256), lds, (hipStream_t)stream, g);
+    if (obs) obs(desc1, stream, 1, g_observer_user);           // (the pair's time is attributed to its second member)
+    ST_CHECK_LAUNCH();
+    return ST_OK;
 }
 
 // All-pairs correlation volume = batched A . B^T on the same MFMA core (K = C = 256 at 512^2).

@@ -30,6 +30,7 @@ from .homography import pack_conv
 # LayerNorm in front of a K = 128 Linear runs inside the row-streaming GEMM (ops.conv_gemm(ln_eps=...)): gamma / beta are
 # folded into the weights at pack time.  ST_FUSE_LN=0 keeps the separate LayerNorm kernel (A/B measurements).
 FUSE_LN = os.environ.get("ST_FUSE_LN", "1") != "0"
+PAIR_CONVS = os.environ.get("ST_PAIR_CONVS", "1") != "0"       # convc2 + convf2 of the motion encoder as one launch
 FUSE_CHAIN = os.environ.get("ST_FUSE_CHAIN", "1") != "0"        # the latent layers' 128-wide tails as one st_linear_chain128 launch
 
 
@@ -492,11 +493,15 @@ class FlowFormer(ParamTree):
         hxA, hxB, corr = S["hxA"], S["hxB"], S["corr"]
         g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
         ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu")
-        # convc2 / convf2 (384 / 128 tiles): no split-K -- with several pairs in flight the other streams fill the idle CUs, and the
-        # slab traffic + reducer launches cost more than they buy (A/B on one box: 78.7 -> 79.0 pairs/s; 69.0 -> 68.5 with one pair in flight)
-        ops.conv_gemm(S["cor1"], D["convc2"][0], S["corflo"][:, :192], geom=g3, bias=D["convc2"][1], act="relu", split_k=1)
         ops.flow_encode(coords1, D["convf1"][0], D["convf1"][1], S["flo1"], hxA[:, 254:256], B, H1, W1)      # :321, gru.py:251,254
-        ops.conv_gemm(S["flo1"], D["convf2"][0], S["corflo"][:, 192:], geom=g3, bias=D["convf2"][1], act="relu", split_k=1)
+        # convc2 (384 tiles) and convf2 (128 tiles) are independent and ready together: one launch, two workgroups per CU, no
+        # split-K slabs (gru.py:252-253)
+        if PAIR_CONVS:
+            ops.conv_gemm_pair((S["cor1"], D["convc2"][0], S["corflo"][:, :192], dict(geom=g3, bias=D["convc2"][1], act="relu")),
+                               (S["flo1"], D["convf2"][0], S["corflo"][:, 192:], dict(geom=g3, bias=D["convf2"][1], act="relu")))
+        else:
+            ops.conv_gemm(S["cor1"], D["convc2"][0], S["corflo"][:, :192], geom=g3, bias=D["convc2"][1], act="relu", split_k=1)
+            ops.conv_gemm(S["flo1"], D["convf2"][0], S["corflo"][:, 192:], geom=g3, bias=D["convf2"][1], act="relu", split_k=1)
         ops.conv_gemm(S["corflo"], D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu")
         # GMA aggregate: v^T = Wv . mf^T, out = mf + gamma * attn @ v
         ops.gma_aggregate(attn, hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], hxA[:, 256:], B, N)

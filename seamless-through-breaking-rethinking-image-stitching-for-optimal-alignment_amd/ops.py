@@ -77,9 +77,10 @@ class workspace_scope:
 
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
               epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, dil=(1, 1), M=None, tile=0, split_k=0, out2=None,
-              ln_eps=None, a2=None, a2_channels=0):
+              ln_eps=None, a2=None, a2_channels=0, _desc_only=False):
     """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
 
+    _desc_only=True returns the filled descriptor without launching (``conv_gemm_pair``).
     a2 / a2_channels: input channels below a2_channels are read from ``a2`` (same shape and row stride as x) instead of x.
 
     ln_eps: the rows of x are layer-normalised (no affine: fold gamma / beta into w / bias, ``fold_layernorm``) inside
@@ -127,11 +128,20 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
         d.a2, d.a2_channels = a2.data_ptr(), int(a2_channels)
     if out2 is not None:
         d.c2, d.ldc2 = out2.data_ptr(), _ld(out2)
+    if _desc_only:
+        return d
     if batch <= 1 and split_k != 1:
         ws = _workspace(x.device)
         d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     check(lib.st_conv_gemm(C.byref(d), _stream()), "st_conv_gemm")
     return out
+
+
+def conv_gemm_pair(call0, call1):
+    """Two independent conv_gemm calls as ONE launch (st_conv_gemm_pair): each argument is (x, w, out, kwargs)."""
+    d0 = conv_gemm(call0[0], call0[1], call0[2], _desc_only=True, **call0[3])
+    d1 = conv_gemm(call1[0], call1[1], call1[2], _desc_only=True, **call1[3])
+    check(lib.st_conv_gemm_pair(C.byref(d0), C.byref(d1), _stream()), "st_conv_gemm_pair")
 
 
 def fold_layernorm(gamma, beta, w, bias=None):

@@ -812,3 +812,26 @@ def test_gemm_second_a_source(ops, kh, kw, ph, pw):
         ops.conv_gemm(dev(xa), dev(w), out, geom=geom, a2=dev(xbn), a2_channels=100)         # not a whole number of 32-channel steps
     with pytest.raises(Exception):
         ops.conv_gemm(dev(xa), dev(w), out, geom=geom, a2=dev(xbn), a2_channels=128, tile=3)  # register-staged kernel: no second source
+
+
+def test_conv_gemm_pair(ops):
+    """st_conv_gemm_pair: two independent convs in one launch (BasicMotionEncoder's convc2 + convf2, gru.py:252-253): bit-identical
+    to the two separate launches, column-slice outputs, different K / N / epilogues; shapes the LDS-DMA kernel cannot take are rejected."""
+    B, H, W = 2, 24, 20
+    gg = g(11)
+    xa, xb = torch.randn(B * H * W, 256, generator=gg), torch.randn(B * H * W, 128, generator=gg)
+    wa, ba = torch.randn(192, 9 * 256, generator=gg) / 48, torch.randn(192, generator=gg)
+    wb, bb = torch.randn(64, 9 * 128, generator=gg) / 34, torch.randn(64, generator=gg)
+    res = torch.randn(B * H * W, 64, generator=gg)
+    geom = (B, H, W, 3, 3, 1, 1, 1, 1)
+    ref, out = torch.zeros(B * H * W, 256, device="cuda"), torch.zeros(B * H * W, 256, device="cuda")
+    ops.conv_gemm(dev(xa), dev(wa), ref[:, :192], geom=geom, bias=dev(ba), act="relu", split_k=1)
+    ops.conv_gemm(dev(xb), dev(wb), ref[:, 192:], geom=geom, bias=dev(bb), act="relu", epi="add", aux1=dev(res), split_k=1)
+    ops.conv_gemm_pair((dev(xa), dev(wa), out[:, :192], dict(geom=geom, bias=dev(ba), act="relu")),
+                       (dev(xb), dev(wb), out[:, 192:], dict(geom=geom, bias=dev(bb), act="relu", epi="add", aux1=dev(res))))
+    assert torch.equal(out, ref)
+    want = F.relu(F.conv2d(xa.view(B, H, W, 256).permute(0, 3, 1, 2).double(), wa.view(192, 3, 3, 256).permute(0, 3, 1, 2).double(), ba.double(), padding=1))
+    assert (out[:, :192].cpu().double() - want.permute(0, 2, 3, 1).reshape(-1, 192)).abs().max() < 3e-5
+    with pytest.raises(Exception):                                                  # Cin = 100: not a whole number of 32-channel steps
+        ops.conv_gemm_pair((dev(xa), dev(wa), out[:, :192], dict(geom=geom)),
+                           (torch.zeros(B * H * W, 100, device="cuda"), torch.zeros(64, 900, device="cuda"), out[:, 192:], dict(geom=geom)))
