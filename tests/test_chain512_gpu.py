@@ -113,9 +113,9 @@ def test_post_pipeline_512_given_oracle_test_out(chain):
     check("chain512_fixed_mask2_flips", g64["mask2_flips"], 15, inclusive=True)             # measured 5 of 302 211 pixels
     check("chain512_fixed_area_mask_flips", g64["area_mask_flips"], 0, inclusive=True)
     check("chain512_fixed_output2_p99", g64["output2_p99"], 0.13)                           # measured 4.4e-2 grey levels
-    check("chain512_fixed_blend_gt1_frac", g64["blend_gt1_frac"], 1e-4)                     # measured 1e-5 (3 bytes: the flipped mask pixels)
+    check("chain512_fixed_blend_gt1_frac", g64["blend_gt1_frac"], 3e-5)                     # measured 1e-5 (3 bytes: the flipped mask pixels)
     check("chain512_fixed_blend_differs_frac", g64["blend_differs_frac"], 5e-3)             # measured 1.7e-3
-    check("chain512_fixed_stitched_p999", g64["stitched_p999"], 2e-2)                       # stitched image in [-1, 1]
+    check("chain512_fixed_stitched_p999", g64["stitched_p999"], 7e-3)                       # stitched image in [-1, 1]
     check("chain512_fixed_learned_mask_p999", g64["learned_mask_p999"], 2e-2)               # (a flipped input-mask pixel moves the net's seam mask locally)
     # against the reference's own (LAPACK-dependent) arithmetic: no further than the fp64-solve oracle is from it
     check("chain512_vs_fp32ref_mask2_flips_over_control", g32["mask2_flips"] / max(1.0, ctl["mask2_flips"]), 1.5)

@@ -198,7 +198,7 @@ def test_quality_psnr_ssim_vs_oracle(model, seeded_sd):
               open(os.path.join(ROOT, "gpurun_out", "r3_parity.json"), "w"), indent=1)
     e2e, ss, osens = summary["end_to_end"], summary["same_start"], summary["oracle_sensitivity"]
     check("quality_e2e_d_psnr_db", e2e["d_psnr"], 0.01, inclusive=True)                   # north_star
-    check("quality_e2e_d_ssim", e2e["d_ssim"], 2e-3, inclusive=True)                      # ~1e3 occlusion pixels of 262144 flip
+    check("quality_e2e_d_ssim", e2e["d_ssim"], 1.7e-3, inclusive=True)                      # ~1e3 occlusion pixels of 262144 flip
     # the end-to-end gap is the amplification of a ~1e-5 px difference of the corner offsets by the seeded random-weight
     # flow network.  Control: the CPU oracle against ITSELF from the HIP path's corner offsets moves by the same amount --
     # the HIP path must not be further from the oracle than a small multiple of the oracle's own sensitivity
@@ -214,4 +214,4 @@ def test_quality_psnr_ssim_vs_oracle(model, seeded_sd):
     # a pixel inside 49 windows x 3 channels)
     check("quality_same_start_d_psnr_db", ss["d_psnr"], 0.005, inclusive=True)
     check("quality_same_start_d_ssim", ss["d_ssim"], 2e-3, inclusive=True)
-    check("quality_same_start_occ_flips", ss["occ_flips"], 400, inclusive=True)
+    check("quality_same_start_occ_flips", ss["occ_flips"], 320, inclusive=True)      # measured 105
