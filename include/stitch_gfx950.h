@@ -65,6 +65,12 @@ typedef struct st_gemm_desc {
                               (Cin % 32 == 0, a2_channels % 32 == 0, batch <= 1); anything else is rejected                 */
     int32_t a2_channels;
     int32_t reserved1;     /* must be 0 */
+    float* c_t;            /* optional TRANSPOSED copy of the result: c_t[n, m] (row stride ld_ct, batch stride batch_stride_c) receives
+                              what c[m, n] receives.  ST_EPI_STORE on the LDS-DMA kernels only, M % 4 == 0, ld_ct % 4 == 0, no split-K:
+                              the all-pairs volume of the reverse flow direction is the transpose of the forward one
+                              (encoder.py:359-369 evaluated for (f2, f1)) and costs a second store instead of a second product */
+    int32_t ld_ct;
+    int32_t reserved2;     /* must be 0 */
 } st_gemm_desc;
 
 /* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.
@@ -128,6 +134,11 @@ int st_abi_chain_desc_size(void);
  *   f1, f2 [B, N, C] channels-last features -> vol [B, N1, N2] = f1 . f2^T (no scaling). */
 int st_corr_volume(const float* f1, const float* f2, float* vol, int32_t B, int32_t N1, int32_t N2,
                    int32_t C, void* stream);
+/* Both directions at once: vol12 [B, N, N] = f1 . f2^T and vol21 [B, N, N] = f2 . f1^T = vol12^T (bit for bit: products
+ * commute, same k order), written by the same launch through a transposed second store (N % 4 == 0, C % 32 == 0, C >= 128;
+ * other shapes run as two products).                                                                                  */
+int st_corr_volume_both(const float* f1, const float* f2, float* vol12, float* vol21, int32_t B, int32_t N, int32_t C,
+                        void* stream);
 
 /* ---- row-wise network ops (channels-last rows) ------------------------------------------------ */
 /* nn.LayerNorm over the last dim (encoder.py:58,140-141; twins.py:752-790, eps 1e-5 / 1e-6).        */

@@ -35,7 +35,8 @@ class GemmDesc(C.Structure):
         + [("tile_cfg", C.c_int32), ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
            ("c2", C.c_void_p), ("ldc2", C.c_int32), ("a_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("reserved0", C.c_int32),
            ("batch_stride_aux1", C.c_int64), ("dh", C.c_int32), ("dw", C.c_int32), ("a_ln", C.c_int32), ("a_ln_eps", C.c_float),
-           ("a2", C.c_void_p), ("a2_channels", C.c_int32), ("reserved1", C.c_int32)]
+           ("a2", C.c_void_p), ("a2_channels", C.c_int32), ("reserved1", C.c_int32),
+           ("c_t", C.c_void_p), ("ld_ct", C.c_int32), ("reserved2", C.c_int32)]
     )
 
 

@@ -197,7 +197,7 @@ __device__ __forceinline__ void gemm_epilogue_load(const st_gemm_desc& d, EpiOpe
     }
 }
 
-template <int TM, int TN, bool LITE = false>
+template <int TM, int TN, bool LITE = false, bool CT = false>
 __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN],
                                                     const EpiOperands<TM, TN>& e, int m0, int n0, int wm, int wn, int li, int lh,
                                                     int split, int kz) {
@@ -267,6 +267,19 @@ __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float
                 if (d.epi == ST_EPI_STORE) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) buf_st(v[r], rc, vc, (unsigned)(ST_EPI_ROW(r) * d.ldc) * 4u);
+                    if (CT && d.c_t) {                           // (only the CT instantiations carry this code)
+                        // transposed copy: the lane's 16 values are 4 runs of 4 consecutive rows of column n -> 4 x 16-byte stores
+                        // into row n of c_t (M % 4 == 0: a run is inside the matrix or wholly outside)
+                        float* ctb = d.c_t + (size_t)(d.batch > 1 ? blockIdx.z : 0) * d.batch_stride_c;
+                        const __amdgpu_buffer_rsrc_t rt = epi_rsrc(ctb, ((long long)(d.N - 1) * d.ld_ct + M) * 4);
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const unsigned vt = (ncol && row0 + 8 * q4 < d.M) ? (unsigned)(n * d.ld_ct + row0 + 8 * q4) * 4u : ST_OOB;
+                            const u32x4 pk = {__float_as_uint(v[4 * q4]), __float_as_uint(v[4 * q4 + 1]), __float_as_uint(v[4 * q4 + 2]),
+                                              __float_as_uint(v[4 * q4 + 3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(pk, rt, (int)vt, 0, 0);
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -544,7 +557,7 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
 // PERSIST (plain matrices, K % (32*STAGES) == 0, no split-K): a workgroup walks M tiles g, g+G, g+2G, ... of its
 // column tile with ONE continuous DMA ring, so the operand tiles of the next M tile stream in under the epilogue
 // of the current one (short-K GEMMs -- K = 128 has four K steps per tile -- are otherwise all load latency).
-template <int WM, int WN, int TM, int TN, int STAGES, bool PERSIST>
+template <int WM, int WN, int TM, int TN, int STAGES, bool PERSIST, bool CT = false>
 __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const int block_id) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, ROWS = BM + BN;
@@ -796,7 +809,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
                     if (kb % KBLK == 0 && kb < nkt) fold();
                 }
                 if (nkt > KBLK) unfold();
-                gemm_epilogue_store<TM, TN>(d, C, acc, eop, (tile_m + mt * G) * BM, n0, wm, wn, li, lh, 1, 0);
+                gemm_epilogue_store<TM, TN, false, CT>(d, C, acc, eop, (tile_m + mt * G) * BM, n0, wm, wn, li, lh, 1, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -822,12 +835,12 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
     }
 #undef ST_GAP
 
-    if (!PERSIST) gemm_epilogue_store<TM, TN>(d, C, acc, eop, m0, n0, wm, wn, li, lh, split, kz);
+    if (!PERSIST) gemm_epilogue_store<TM, TN, false, CT>(d, C, acc, eop, m0, n0, wm, wn, li, lh, split, kz);
 }
 
-template <int WM, int WN, int TM, int TN, int STAGES, bool PERSIST>
+template <int WM, int WN, int TM, int TN, int STAGES, bool PERSIST, bool CT = false>
 __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const st_gemm_desc d) {
-    conv_gemm_dma_body<WM, WN, TM, TN, STAGES, PERSIST>(d, (int)blockIdx.x);
+    conv_gemm_dma_body<WM, WN, TM, TN, STAGES, PERSIST, CT>(d, (int)blockIdx.x);
 }
 
 // Two independent contractions in ONE launch (st_conv_gemm_pair): workgroups [0, tiles0) run d[0], the rest d[1].  For pairs of
@@ -1371,7 +1384,7 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
     if (plain && !d.a2 && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
         int G = slots / ntn;
         if (G > ntm) G = ntm;
-        auto k = conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true>;
+        auto k = d.c_t ? conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true, true> : conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_last_plan[3] = 1;
         hipLaunchKernelGGL(k, dim3(G * ntn, 1, batch), dim3(256), lds, s, d);
@@ -1379,7 +1392,7 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
         return ST_OK;
     }
     dim3 grid(ntm * ntn, 1, d.split_k > 1 ? d.split_k : batch);
-    auto k = conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, false>;
+    auto k = d.c_t ? conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, false, true> : conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, d);
     if (d.split_k > 1)
@@ -1422,7 +1435,10 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
-    if (d.reserved0 != 0 || d.reserved1 != 0) return ST_EINVAL;
+    if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0) return ST_EINVAL;
+    if (d.c_t && (d.epi != ST_EPI_STORE || (d.M & 3) || (d.ld_ct & 3) || d.ld_ct < d.M || ((uintptr_t)d.c_t & 15) || d.split_k > 1 || d.a_ln ||
+                  (int64_t)d.N * d.ld_ct * 4 >= ((int64_t)1 << 31)))
+        return ST_EINVAL;
     if (d.a2 && (d.a2_channels <= 0 || d.a2_channels % 32 || d.a2_channels > d.Cin || d.batch > 1 || ((uintptr_t)d.a2 & 15))) return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // byte extents of one batch slice of A and W for the buffer descriptors (must stay below 2 GiB so the
@@ -1443,7 +1459,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         if (ab >= (int64_t)ST_OOB || ((int64_t)d.M + 256) * ldmax * 4 >= lim) {
             // Larger than the 32-bit offsets reach (whole-batch PatchEmbed maps at B >= 4, ...): run the rows in chunks.
             // A chunk is a whole number of images (convs) and of aux0 mapping periods, so every operand just shifts its base.
-            if ((d.batch > 1) || d.split_k > 1) return ST_EINVAL;
+            if ((d.batch > 1) || d.split_k > 1 || d.c_t) return ST_EINVAL;
             const int64_t div = d.aux0_row_div > 1 ? d.aux0_row_div : 1, mod = d.aux0_row_mod > 0 ? d.aux0_row_mod : 1;
             int64_t unit = hw;                                           // rows per indivisible unit
             {
@@ -1487,13 +1503,13 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
                          (d.ldw % 4 == 0) && (d.Cin % 4 == 0) &&
                          (d.batch_stride_a % 4 == 0) && (d.batch_stride_w % 4 == 0);
     const int batch = d.batch > 0 ? d.batch : 1;
-    if (d.M <= 8 && d.kh == 1 && d.kw == 1 && aligned && batch == 1 && d.epi == ST_EPI_STORE && !d.aux0 && d.H * d.W == d.M && !d.a2) {
+    if (d.M <= 8 && d.kh == 1 && d.kw == 1 && aligned && batch == 1 && d.epi == ST_EPI_STORE && !d.aux0 && d.H * d.W == d.M && !d.a2 && !d.c_t) {
         g_last_plan[0] = 0; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 0;
         hipLaunchKernelGGL(skinny_gemm_kernel<8>, dim3((d.N * 64 + 255) / 256), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;
     }
-    if (d.N <= 4 && aligned && batch == 1 && d.epi != ST_EPI_ZR && d.M >= 1024 && d.tile_cfg == 0 && d.split_k <= 1 && !d.a2) {
+    if (d.N <= 4 && aligned && batch == 1 && d.epi != ST_EPI_ZR && d.M >= 1024 && d.tile_cfg == 0 && d.split_k <= 1 && !d.a2 && !d.c_t) {
         g_last_plan[0] = 1; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 0;
         if (d.N <= 2 && d.Cin == 256 && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 && d.dh <= 1 && d.dw <= 1 &&
             d.Ho == d.H && d.Wo == d.W) {
@@ -1512,7 +1528,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && (int64_t)d.H * d.W == d.M;
         const bool map_ok = (d.aux0_row_div <= 1 && (d.aux0_row_mod <= 0 || d.aux0_row_mod % 32 == 0)) ||
                             (d.aux0_row_div == 8 && d.aux0_row_mod <= 0) || !d.aux0;
-        const bool rs_ok = plain && aligned && batch == 1 && !d.a2 && d.split_k <= 1 && (d.K == 64 || d.K == 128) &&
+        const bool rs_ok = plain && aligned && batch == 1 && !d.a2 && !d.c_t && d.split_k <= 1 && (d.K == 64 || d.K == 128) &&
                            d.epi != ST_EPI_ZR && d.epi != ST_EPI_GRU && map_ok;
         // measured on MI355X, in the pipeline and stand-alone (tools/rowstream_bench.py): ahead of the LDS-DMA kernel for K = 64,
         // for M >= 262144 and for N >= 384; behind it by ~2 us per launch at M <= 65536, N = 128 (one block per wave: all
@@ -1543,7 +1559,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         else cfg = dma ? 13 : 3;
     }
     if (cfg > 10 && !dma_ok) return ST_EINVAL;
-    if (d.a2 && cfg <= 10) return ST_EINVAL;                   // the second A source exists in the LDS-DMA kernel only
+    if ((d.a2 || d.c_t) && cfg <= 10) return ST_EINVAL;        // second A source / transposed copy: LDS-DMA kernels only
     // split-K: a launch that cannot fill the 256 CUs (M = 4096-pixel maps x 64..256 channels) is cut
     // along K into slabs reduced by a second tiny kernel (deterministic order; no atomics).
     static const int bms[5] = {0, 128, 128, 64, 128}, bns[5] = {0, 128, 64, 64, 32};
@@ -1551,7 +1567,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     int split = d.split_k;
     if (split == 0) {
         split = 1;
-        if (batch == 1 && d.workspace && d.K >= 512) {
+        if (batch == 1 && d.workspace && d.K >= 512 && !d.c_t) {
             if (cfg > 10) {
                 // the pipelined kernel runs near its steady-state rate with ONE workgroup per CU, so it only needs
                 // every CU covered; 257..511 tiles leave half the chip with twice the work of the other half
@@ -1590,7 +1606,7 @@ static int pair_member_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
     if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
-    if (d.reserved0 != 0 || d.reserved1 != 0 || d.a_ln || d.batch > 1 || d.split_k > 1 || (d.tile_cfg != 0 && d.tile_cfg != 13)) return ST_EINVAL;
+    if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0 || d.c_t || d.a_ln || d.batch > 1 || d.split_k > 1 || (d.tile_cfg != 0 && d.tile_cfg != 13)) return ST_EINVAL;
     if (d.a2 && (d.a2_channels <= 0 || d.a2_channels % 32 || d.a2_channels > d.Cin || ((uintptr_t)d.a2 & 15))) return ST_EINVAL;
     if (((uintptr_t)d.a & 15) || ((uintptr_t)d.w & 15) || (d.ldx & 3) || (d.ldw & 3)) return ST_EINVAL;
     const bool plain_mat = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && (int64_t)d.H * d.W == d.M &&
@@ -1642,6 +1658,25 @@ extern "C" int st_corr_volume(const float* f1, const float* f2, float* vol, int3
     d.ldw = C; d.ldc = N2; d.alpha = 1.0f;
     d.batch = B; d.batch_stride_a = (int64_t)N1 * C; d.batch_stride_w = (int64_t)N2 * C;
     d.batch_stride_c = (int64_t)N1 * N2;
+    return st_conv_gemm(&d, stream);
+}
+
+extern "C" int st_corr_volume_both(const float* f1, const float* f2, float* vol12, float* vol21, int32_t B, int32_t N, int32_t C,
+                                   void* stream) {
+    if (!f1 || !f2 || !vol12 || !vol21 || B <= 0 || N <= 0 || C <= 0) return ST_EINVAL;
+    if ((N & 3) || C % 32 || C < 128 || (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)vol21) & 15)) {
+        // not a shape of the LDS-DMA kernel (which carries the transposed store): two products
+        const int rc = st_corr_volume(f1, f2, vol12, B, N, N, C, stream);
+        return rc ? rc : st_corr_volume(f2, f1, vol21, B, N, N, C, stream);
+    }
+    st_gemm_desc d = {};
+    d.a = f1; d.w = f2; d.c = vol12; d.c_t = vol21; d.ld_ct = N;
+    d.M = N; d.N = N; d.K = C;
+    d.H = 1; d.W = N; d.Cin = C; d.ldx = C;
+    d.kh = d.kw = 1; d.sh = d.sw = 1; d.ph = d.pw = 0; d.Ho = 1; d.Wo = N;
+    d.ldw = C; d.ldc = N; d.alpha = 1.0f;
+    d.batch = B; d.batch_stride_a = (int64_t)N * C; d.batch_stride_w = (int64_t)N * C;
+    d.batch_stride_c = (int64_t)N * N;
     return st_conv_gemm(&d, stream);
 }
 

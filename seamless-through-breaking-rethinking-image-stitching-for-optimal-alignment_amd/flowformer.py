@@ -608,8 +608,8 @@ class FlowFormer(ParamTree):
         N = H1 * W1
         feats = feats.view(2, B, N, 256)
         cost_maps = torch.empty((2 * B * N, N), device=dev)
-        ops.corr_volume(feats[0], feats[1], cost_maps[:B * N].view(B, N, N))
-        ops.corr_volume(feats[1], feats[0], cost_maps[B * N:].view(B, N, N))
+        # the reverse direction's volume is the transpose of the forward one: one product, two stores
+        ops.corr_volume_both(feats[0], feats[1], cost_maps[:B * N].view(B, N, N), cost_maps[B * N:].view(B, N, N))
         mem, short = self._cost_encoder(cost_maps, ctx, 2 * B, H1, W1)
         flow_up, coords1 = self._decoder(mem, short, ctx, cost_maps, 2 * B, H1, W1, iters)
         return flow_up, coords1, (2 * B, H1, W1)

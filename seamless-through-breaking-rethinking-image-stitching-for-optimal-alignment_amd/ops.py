@@ -188,6 +188,13 @@ def corr_volume(f1, f2, out):
     return out
 
 
+def corr_volume_both(f1, f2, out12, out21):
+    """out12 = f1 . f2^T and out21 = f2 . f1^T (= out12^T) from one launch."""
+    B, N, Cc = f1.shape
+    check(lib.st_corr_volume_both(_p(f1), _p(f2), _pc(out12), _pc(out21), B, N, Cc, _stream()), "st_corr_volume_both")
+    return out12, out21
+
+
 def layernorm(x, w, b, out, eps):
     check(lib.st_layernorm(_p(x), _ld(x), _p(w), _p(b), _p(out), _ld(out), x.shape[0], x.shape[1], eps, _stream()),
           "st_layernorm")

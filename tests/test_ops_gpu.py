@@ -835,3 +835,18 @@ def test_conv_gemm_pair(ops):
     with pytest.raises(Exception):                                                  # Cin = 100: not a whole number of 32-channel steps
         ops.conv_gemm_pair((dev(xa), dev(wa), out[:, :192], dict(geom=geom)),
                            (torch.zeros(B * H * W, 100, device="cuda"), torch.zeros(64, 900, device="cuda"), out[:, 192:], dict(geom=geom)))
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 4096, 256), (1, 192, 256), (3, 100, 64)])
+def test_corr_volume_both(ops, B, N, C):
+    """st_corr_volume_both: the reverse direction's all-pairs volume (encoder.py:359-369 for (f2, f1)) is the transpose of the forward
+    one and comes out of the same launch through a transposed second store -- bit-identical to two st_corr_volume launches."""
+    gg = g(21)
+    f1, f2 = torch.randn(B, N, C, generator=gg).cuda(), torch.randn(B, N, C, generator=gg).cuda()
+    r12, r21 = torch.empty(B, N, N, device="cuda"), torch.empty(B, N, N, device="cuda")
+    ops.corr_volume(f1, f2, r12)
+    ops.corr_volume(f2, f1, r21)
+    both = torch.full((2 * B, N, N), 7.0, device="cuda")
+    ops.corr_volume_both(f1, f2, both[:B], both[B:])
+    assert torch.equal(both[:B], r12) and torch.equal(both[B:], r21)
+    assert torch.equal(both[B:], r12.transpose(1, 2))
