@@ -112,21 +112,24 @@ def instrumented_step(run_step):
             rec.append((flops, abytes, e0, ev))
 
     lib.st_set_gemm_observer(C.cast(observer, C.c_void_p), None)
+    st = torch.cuda.current_stream()
+    empties = []
     try:
+        # hold the stream back (~0.1 s spin kernel) while the host enqueues the whole eager step: the GPU then runs the ~1000
+        # launches back to back and a bracket reads its kernel(s) + the event overhead, not the Python launch latency that an idle
+        # GPU would otherwise wait for in front of every short kernel
+        torch.cuda._sleep(int(2.4e8))
         run_step()
+        # what an EMPTY event bracket reads (two back-to-back records are a few us apart on the GPU timeline): every bracket above
+        # carries that on top of its kernel(s); subtract the median
+        for _ in range(64):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            e1.record(st)
+            empties.append((e0, e1))
         torch.cuda.synchronize()
     finally:
         lib.st_set_gemm_observer(None, None)
-    # what an EMPTY event bracket reads on this stream: two back-to-back records are ~2-3 us apart on the GPU timeline, and
-    # every bracket above carries that on top of its kernel(s); subtract the median
-    st = torch.cuda.current_stream()
-    empties = []
-    for _ in range(64):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        e1.record(st)
-        empties.append((e0, e1))
-    torch.cuda.synchronize()
     ov = sorted(e0.elapsed_time(e1) for e0, e1 in empties)[len(empties) // 2]
     raw = [r[2].elapsed_time(r[3]) for r in rec]
     return dict(flops=sum(r[0] for r in rec), ms_raw=sum(raw), ms=sum(max(0.0, t - ov) for t in raw), launches=len(rec),

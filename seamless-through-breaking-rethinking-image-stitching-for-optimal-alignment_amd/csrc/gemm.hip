@@ -1635,8 +1635,11 @@ extern "C" int st_conv_gemm_pair(const st_gemm_desc* desc0, const st_gemm_desc* 
     g.tiles0 = tiles(g.d[0]);
     const int total = g.tiles0 + tiles(g.d[1]);
     st_gemm_observer_fn obs = g_observer;
+    // plan[3]: 2 = first member of a pair (no dispatch of its own: the observer sees an empty bracket), 3 = second member (the
+    // pair's single dispatch and all of its time)
+    g_last_plan[0] = 3; g_last_plan[1] = 13; g_last_plan[2] = 1; g_last_plan[3] = 2;
     if (obs) { obs(desc0, stream, 0, g_observer_user); obs(desc0, stream, 1, g_observer_user); obs(desc1, stream, 0, g_observer_user); }
-    g_last_plan[0] = 3; g_last_plan[1] = 13; g_last_plan[2] = 1; g_last_plan[3] = 0;
+    g_last_plan[3] = 3;
     auto k = conv_gemm_dma_pair_kernel<2, 2, 1, 1, 4>;
     const size_t lds = (size_t)4 * (64 + 64) * 32 * sizeof(float);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

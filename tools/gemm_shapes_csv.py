@@ -123,15 +123,16 @@ def join(out_csv, launches_json, fetch_csv, write_csv_path):
         rows.sort()
         return rows
     F, Wr = gemm_rows(fetch_csv), gemm_rows(write_csv_path)
-    per_step = len(rec) + sum(1 for r in rec if r["split_k"] > 1)
+    ndisp = lambda r: 0 if r["persist"] == 2 else (2 if r["split_k"] > 1 else 1)          # noqa: E731  (pair member 0: no dispatch of its own)
+    per_step = sum(ndisp(r) for r in rec)
     # the profiled command runs 2 warm-up steps + the instrumented one: keep the dispatches of the LAST step
     for rows in (F, Wr):
         assert len(rows) >= per_step, (len(rows), per_step)          # the first warm-up step also builds cached constant tables
     F, Wr = F[-per_step:], Wr[-per_step:]
     i = 0
     for r in rec:
-        n = 2 if r["split_k"] > 1 else 1
-        assert "splitk_reduce" not in F[i][1] and (n == 1 or "splitk_reduce" in F[i + 1][1]), (i, F[i], r)
+        n = ndisp(r)
+        assert n == 0 or ("splitk_reduce" not in F[i][1] and (n == 1 or "splitk_reduce" in F[i + 1][1])), (i, F[i], r)
         r["fetch_bytes"] = sum(v for _, _, v in F[i:i + n]) * 1024 * 2          # gfx950: FETCH_SIZE tallies wide reads at half size
         r["write_bytes"] = sum(v for _, _, v in Wr[i:i + n]) * 1024
         i += n
