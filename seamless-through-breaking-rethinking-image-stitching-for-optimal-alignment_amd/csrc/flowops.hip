@@ -1,6 +1,7 @@
 // FlowFormer++ decoder gather kernels on gfx950: 9x9 cost lookup, convex 8x upsampling, coordinate
 // bookkeeping.  Pure gather / HBM-bound work; lanes of a wave walk contiguous addresses.
 #include "common.h"
+#include <type_traits>
 #include "../../include/stitch_gfx950.h"
 
 // coords0 = (x, y) pixel grid, channels-last [B*H*W, 2]   (decoder.py:22-29 initialize_flow)
@@ -305,8 +306,21 @@ __device__ __forceinline__ void tc_layernorm(f32x4 v[4], const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restrict__ corr, int ldc, const float* __restrict__ coords1,
-                                                                  const float* __restrict__ kv, TokenChainArgs A, int rows, int ntok) {
+template <int I, int N, class F>
+__device__ __forceinline__ void tc_static_for(F&& f) {       // literal indices: the staging arrays become registers before any scheduling
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); tc_static_for<I + 1, N>(f); }
+}
+
+// Memory schedule: the kernel runs ONE wave per SIMD and has nothing to hide a memory round trip behind, so its global operands are
+// requested in two batches of unconditional loads (a row / token out of range reads a clamped address and is masked in the arithmetic:
+// hipcc turns `cond ? *p : 0` into load / s_waitcnt vmcnt(0) pairs, and the previous form of this kernel paid 40 dependent L2 round
+// trips -- tools/isa_waits.py): first the wave's 16 cost rows, its coords, the six weight matrices and the ten bias / LayerNorm vectors,
+// all staged into LDS; then, once those registers are free, the k AND v slices of its rows' memory tokens (64 float4 per lane, parked
+// in the register file the single wave owns), which land under the first three products.  After the one barrier the chain runs on
+// registers and LDS only; its single store is the result.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void decoder_token_chain_kernel(float* __restrict__ corr, int ldc, const float* __restrict__ coords1,
+                                                                     const float* __restrict__ kv, TokenChainArgs A, int rows, int ntok) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* W0 = sm;                                  // [64][TC_LDW0]
     float* W2 = W0 + 64 * TC_LDW0;                   // five [64][TC_LDW]
@@ -314,63 +328,102 @@ __global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restr
     float* Wp = Wq + 64 * TC_LDW;
     float* Wf0 = Wp + 64 * TC_LDW;
     float* Wf3 = Wf0 + 64 * TC_LDW;
-    float* Xall = Wf3 + 64 * TC_LDW;                 // 2 waves x [16][TC_LDW0]
+    float* Vec = Wf3 + 64 * TC_LDW;                  // ten 64-float vectors: b0 b2 n1w n1b bq bp n2w n2b bf0 bf3
+    float* Xall = Vec + 10 * 64;                     // NW waves x [16][TC_LDW0]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NT = 128;                          // 2 waves per workgroup -> 256 workgroups at 8192 rows
-    // weights -> LDS: all of a matrix's 16-B loads are issued before the first LDS write (independent loads
-    // in flight together; a load->store loop serialised ~50 L2 round trips per workgroup)
-    {
-        float4 v[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {               // first layer: 64 x 24 float4 (84 real columns = 21, zero up to 96)
-            const int e = tid + NT * i, n = e / 24, k4 = e % 24;
-            v[i] = k4 < 21 ? *reinterpret_cast<const float4*>(A.w0 + n * 84 + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int e = tid + NT * i, n = e / 24, k4 = e % 24;
-            *reinterpret_cast<float4*>(W0 + n * TC_LDW0 + 4 * k4) = v[i];
-        }
-        const float* src[5] = {A.w2, A.wq, A.wp, A.wf0, A.wf3};
-        float* dst[5] = {W2, Wq, Wp, Wf0, Wf3};
-#pragma unroll
-        for (int m = 0; m < 5; ++m) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(src[m] + 4 * (tid + NT * i));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = tid + NT * i, n = e >> 4, k4 = e & 15;
-                *reinterpret_cast<float4*>(dst[m] + n * TC_LDW + 4 * k4) = v[i];
-            }
-        }
-    }
+    constexpr int NT = 64 * NW;                      // NW waves per workgroup, 16 rows each
     float* X = Xall + wave * 16 * TC_LDW0;
-    const int row0 = (blockIdx.x * 2 + wave) * 16;
-    // stage this wave's 16 cost_forward rows (84 wide = 21 float4, zero padded to 96); corr rows are 16-B aligned
-    {
-        float4 v[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int e = lane + 64 * i, r = e / 24, k4 = e % 24;
-            const int row = row0 + r;
-            v[i] = (row < rows && k4 < 21) ? *reinterpret_cast<const float4*>(corr + (size_t)row * ldc + 4 * k4)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int e = lane + 64 * i, r = e / 24, k4 = e % 24;
-            *reinterpret_cast<float4*>(X + r * TC_LDW0 + 4 * k4) = v[i];
-        }
-    }
-    __syncthreads();
+    const int row0 = (blockIdx.x * NW + wave) * 16;
     const int c = lane & 15, g = lane >> 4;
+    const int jmax = ntok - 1;
+
+    // ---- batch 1: cost rows, weights, vectors, coords
+    constexpr int P0 = 1536 / NT, P1 = 1024 / NT, NVEC = (160 + NT - 1) / NT;
+    float4 xv[6], w0v[P0];
+    f32x4 wv[5 * P1], vecv[NVEC];        // (first-class vectors: a float4 copied global -> array -> LDS stays a memcpy chain through the stack)
+    float cx[4], cy[4];
+    tc_static_for<0, NVEC>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int e = min(tid + NT * i, 159), q = e >> 4;
+        const float* vp = q == 0 ? A.b0 : q == 1 ? A.b2 : q == 2 ? A.n1w : q == 3 ? A.n1b : q == 4 ? A.bq : q == 5 ? A.bp : q == 6 ? A.n2w
+                          : q == 7 ? A.n2b : q == 8 ? A.bf0 : A.bf3;
+        vecv[i] = *reinterpret_cast<const f32x4*>(vp + 4 * (e & 15));
+    });
+    tc_static_for<0, 6>([&](auto ic) {               // 16 cost_forward rows (84 wide = 21 float4, zero padded to 96); rows are 16-B aligned
+        constexpr int i = decltype(ic)::value;
+        const int e = lane + 64 * i, r = e / 24, k4 = e % 24;
+        xv[i] = *reinterpret_cast<const float4*>(corr + (size_t)min(row0 + r, rows - 1) * ldc + 4 * min(k4, 20));
+    });
+    tc_static_for<0, P0>([&](auto ic) {              // first layer: 64 x 24 float4 (84 real columns = 21, zero up to 96)
+        constexpr int i = decltype(ic)::value;
+        const int e = tid + NT * i, n = e / 24, k4 = e % 24;
+        w0v[i] = *reinterpret_cast<const float4*>(A.w0 + n * 84 + 4 * min(k4, 20));
+    });
+    tc_static_for<0, P1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int off = 4 * (tid + NT * i);
+        wv[5 * i + 0] = *reinterpret_cast<const f32x4*>(A.w2 + off);
+        wv[5 * i + 1] = *reinterpret_cast<const f32x4*>(A.wq + off);
+        wv[5 * i + 2] = *reinterpret_cast<const f32x4*>(A.wp + off);
+        wv[5 * i + 3] = *reinterpret_cast<const f32x4*>(A.wf0 + off);
+        wv[5 * i + 4] = *reinterpret_cast<const f32x4*>(A.wf3 + off);
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float2 p2 = *reinterpret_cast<const float2*>(coords1 + (size_t)min(row0 + 4 * g + r, rows - 1) * 2);
+        cx[r] = p2.x; cy[r] = p2.y;
+    }
+    // ---- -> LDS
+    tc_static_for<0, 6>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int e = lane + 64 * i, r = e / 24, k4 = e % 24;
+        *reinterpret_cast<float4*>(X + r * TC_LDW0 + 4 * k4) = k4 < 21 ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    });
+    tc_static_for<0, P0>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int e = tid + NT * i, n = e / 24, k4 = e % 24;
+        *reinterpret_cast<float4*>(W0 + n * TC_LDW0 + 4 * k4) = k4 < 21 ? w0v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    });
+    tc_static_for<0, P1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int e = tid + NT * i, n = e >> 4, k4 = e & 15, off = n * TC_LDW + 4 * k4;
+        *reinterpret_cast<f32x4*>(W2 + off) = wv[5 * i + 0];
+        *reinterpret_cast<f32x4*>(Wq + off) = wv[5 * i + 1];
+        *reinterpret_cast<f32x4*>(Wp + off) = wv[5 * i + 2];
+        *reinterpret_cast<f32x4*>(Wf0 + off) = wv[5 * i + 3];
+        *reinterpret_cast<f32x4*>(Wf3 + off) = wv[5 * i + 4];
+    });
+    tc_static_for<0, NVEC>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int e = tid + NT * i;
+        if (e < 160) *reinterpret_cast<f32x4*>(Vec + 4 * e) = vecv[i];
+    });
+    // ---- batch 2: lane (row = lane & 15, quarter g) owns columns 16g .. 16g+15 = two heads of its row: that slice of the row's k / v
+    // tokens, first read three products later
+    asm volatile("" ::: "memory");
+    float4 kk[8][4], vv[8][4];
+    {
+        const float* kvr = kv + (size_t)min(row0 + c, rows - 1) * ntok * 128 + 16 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kk[j][e] = *reinterpret_cast<const float4*>(kvr + min(j, jmax) * 128 + 4 * e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[j][e] = *reinterpret_cast<const float4*>(kvr + min(j, jmax) * 128 + 64 + 4 * e);
+    }
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    const float *b0 = Vec, *b2 = Vec + 64, *n1w = Vec + 128, *n1b = Vec + 192, *bq = Vec + 256, *bp = Vec + 320, *n2w = Vec + 384,
+                *n2b = Vec + 448, *bf0 = Vec + 512, *bf3 = Vec + 576;
     f32x4 acc[4], query[4], x[4];
     // ---- flow_token_encoder
     tc_gemm<96, TC_LDW0, TC_LDW0>(X, W0, acc, lane);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + A.b0[16 * t + c], ST_ACT_GELU);
+        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + b0[16 * t + c], ST_ACT_GELU);
     __builtin_amdgcn_wave_barrier();
     tc_store(X, acc, lane);
     __builtin_amdgcn_wave_barrier();
@@ -378,16 +431,14 @@ __global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restr
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) query[t][r] += A.b2[16 * t + c];
+        for (int r = 0; r < 4; ++r) query[t][r] += b2[16 * t + c];
     // ---- LN1 + sine PE of coords1 (tile t = sin x | cos x | sin y | cos y, band = c)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = query[t];
-    tc_layernorm(acc, A.n1w, A.n1b, lane);
+    tc_layernorm(acc, n1w, n1b, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = min(row0 + 4 * g + r, rows - 1);
-        const float px = coords1[(size_t)row * 2], py = coords1[(size_t)row * 2 + 1];
-        const float ax = ((3.14f * px) * (float)c) * 0.005f, ay = ((3.14f * py) * (float)c) * 0.005f;
+        const float ax = ((3.14f * cx[r]) * (float)c) * 0.005f, ay = ((3.14f * cy[r]) * (float)c) * 0.005f;
         acc[0][r] += sinf(ax); acc[1][r] += cosf(ax); acc[2][r] += sinf(ay); acc[3][r] += cosf(ay);
     }
     __builtin_amdgcn_wave_barrier();
@@ -396,19 +447,17 @@ __global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restr
     tc_gemm<64, TC_LDW, TC_LDW>(X, Wq, acc, lane);                       // q
     // ---- 8-head attention over the pixel's ntok memory tokens (head = column / 8), in ROW layout: q goes back
     // to the slab, then lane (row = lane&15, quarter = lane>>4) owns columns 16*quarter..+15 = two heads of its row
-    // and streams that slice of the row's k / v tokens with 16-B loads (no cross-lane traffic at all).
+    // (no cross-lane traffic at all).
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] += A.bq[16 * t + c];
+        for (int r = 0; r < 4; ++r) acc[t][r] += bq[16 * t + c];
     __builtin_amdgcn_wave_barrier();
     tc_store(X, acc, lane);
     __builtin_amdgcn_wave_barrier();
     {
         const float scale = 0.35355339059327373f;                         // 8^-0.5
         const int arow = lane & 15;
-        const int grow = min(row0 + arow, rows - 1);
-        const float* kvr = kv + (size_t)grow * ntok * 128 + 16 * g;
         float qv[16], o[16];
 #pragma unroll
         for (int e = 0; e < 16; e += 4) {
@@ -419,16 +468,11 @@ __global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float a0 = 0.f, a1 = 0.f;
-            if (j < ntok) {
-                float kk[16];
+            float kf[16];
 #pragma unroll
-                for (int e = 0; e < 16; e += 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(kvr + j * 128 + e);
-                    kk[e] = t4.x; kk[e + 1] = t4.y; kk[e + 2] = t4.z; kk[e + 3] = t4.w;
-                }
+            for (int e = 0; e < 4; ++e) { kf[4 * e] = kk[j][e].x; kf[4 * e + 1] = kk[j][e].y; kf[4 * e + 2] = kk[j][e].z; kf[4 * e + 3] = kk[j][e].w; }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { a0 = fmaf(qv[e], kk[e], a0); a1 = fmaf(qv[8 + e], kk[8 + e], a1); }
-            }
+            for (int e = 0; e < 8; ++e) { a0 = fmaf(qv[e], kf[e], a0); a1 = fmaf(qv[8 + e], kf[8 + e], a1); }
             s0[j] = j < ntok ? a0 * scale : -INFINITY;
             s1[j] = j < ntok ? a1 * scale : -INFINITY;
         }
@@ -440,16 +484,15 @@ __global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restr
         for (int e = 0; e < 16; ++e) o[e] = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (j < ntok) {
-                const float p0 = expf(s0[j] - m0), p1 = expf(s1[j] - m1);
-                d0 += p0; d1 += p1;
+            // (a token past ntok has s = -inf: p = exp(-inf) = 0 exactly, and its clamped v adds +0)
+            const float p0 = expf(s0[j] - m0), p1 = expf(s1[j] - m1);
+            d0 += p0; d1 += p1;
 #pragma unroll
-                for (int e = 0; e < 16; e += 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(kvr + j * 128 + 64 + e);
-                    const float pe = e < 8 ? p0 : p1;
-                    o[e] = fmaf(pe, t4.x, o[e]); o[e + 1] = fmaf(pe, t4.y, o[e + 1]);
-                    o[e + 2] = fmaf(pe, t4.z, o[e + 2]); o[e + 3] = fmaf(pe, t4.w, o[e + 3]);
-                }
+            for (int e = 0; e < 4; ++e) {
+                const float4 t4 = vv[j][e];
+                const float pe = e < 2 ? p0 : p1;
+                o[4 * e] = fmaf(pe, t4.x, o[4 * e]); o[4 * e + 1] = fmaf(pe, t4.y, o[4 * e + 1]);
+                o[4 * e + 2] = fmaf(pe, t4.z, o[4 * e + 2]); o[4 * e + 3] = fmaf(pe, t4.w, o[4 * e + 3]);
             }
         }
         const float i0 = 1.0f / d0, i1 = 1.0f / d1;
@@ -463,11 +506,11 @@ __global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restr
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[t][r] = query[t][r] + (acc[t][r] + A.bp[16 * t + c]);     // short_cut + proj
+        for (int r = 0; r < 4; ++r) x[t][r] = query[t][r] + (acc[t][r] + bp[16 * t + c]);     // short_cut + proj
     // ---- FFN
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = x[t];
-    tc_layernorm(acc, A.n2w, A.n2b, lane);
+    tc_layernorm(acc, n2w, n2b, lane);
     __builtin_amdgcn_wave_barrier();
     tc_store(X, acc, lane);
     __builtin_amdgcn_wave_barrier();
@@ -475,7 +518,7 @@ __global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restr
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + A.bf0[16 * t + c], ST_ACT_GELU);
+        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + bf0[16 * t + c], ST_ACT_GELU);
     __builtin_amdgcn_wave_barrier();
     tc_store(X, acc, lane);
     __builtin_amdgcn_wave_barrier();
@@ -485,7 +528,7 @@ __global__ __launch_bounds__(128) void decoder_token_chain_kernel(float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row0 + 4 * g + r;
-            if (row < rows) corr[(size_t)row * ldc + 84 + 16 * t + c] = x[t][r] + (acc[t][r] + A.bf3[16 * t + c]);
+            if (row < rows) corr[(size_t)row * ldc + 84 + 16 * t + c] = x[t][r] + (acc[t][r] + bf3[16 * t + c]);
         }
 }
 
@@ -495,10 +538,13 @@ extern "C" int st_decoder_token_chain(float* corr, int32_t ld_corr, const float*
     TokenChainArgs A;
     const float** dst = reinterpret_cast<const float**>(&A);
     for (int i = 0; i < 16; ++i) { if (!weights16[i]) return ST_EINVAL; dst[i] = weights16[i]; }
-    const size_t lds = (size_t)(64 * TC_LDW0 + 5 * 64 * TC_LDW + 2 * 16 * TC_LDW0) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)decoder_token_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(decoder_token_chain_kernel, dim3((rows + 31) / 32), dim3(128), lds, (hipStream_t)stream, corr, ld_corr, coords1, kv,
-                       A, rows, ntok);
+    // 4 waves (64 rows) per workgroup: 128 workgroups at 8192 rows -- the kernel holds 128 KB of LDS, so it keeps the CUs it runs on
+    // to itself; on half the chip it leaves the other half to the GEMM workgroups of the other pairs in flight
+    constexpr int NW = 4;
+    const size_t lds = (size_t)(64 * TC_LDW0 + 5 * 64 * TC_LDW + 640 + NW * 16 * TC_LDW0) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)decoder_token_chain_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(decoder_token_chain_kernel<NW>, dim3((rows + 16 * NW - 1) / (16 * NW)), dim3(64 * NW), lds, (hipStream_t)stream, corr, ld_corr,
+                       coords1, kv, A, rows, ntok);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

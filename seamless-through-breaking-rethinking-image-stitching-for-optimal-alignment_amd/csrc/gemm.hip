@@ -1285,38 +1285,46 @@ __global__ __launch_bounds__(256) void narrow_conv3x3_kernel(const st_gemm_desc 
     if (wid >= nimg * d.H * segs) return;
     const int b = wid / (d.H * segs), r = wid - b * d.H * segs;
     const int y = r / segs, x0 = (r - y * segs) * 8;
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, (int)d.w_bytes, 0x00020000);
     float4 wv[NOUT][9];
 #pragma unroll
     for (int n = 0; n < NOUT; ++n)
 #pragma unroll
         for (int t = 0; t < 9; ++t)
-            wv[n][t] = n < d.N ? *reinterpret_cast<const float4*>(d.w + (size_t)n * d.ldw + t * 256 + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[n][t] = buf_load16(rsrcW, n < d.N ? (unsigned)(n * d.ldw + t * 256 + 4 * lane) * 4u : ST_OOB);   // (a conditional global load made
+    //                                                       hipcc wait for each of the 18 loads in turn: 18 dependent L2 round trips per wave)
     float acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    // all 30 input rows are requested before the first is used (raw buffer loads: a tap outside the image gets an offset past
+    // num_records and reads zeros, so there is no branch between the loads): one memory round trip per wave instead of three
+    // dependent ones -- with one wave per SIMD nothing else hides them
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.a), 0, (int)d.a_bytes, 0x00020000);
+    float4 in[3][10];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = y + ky - 1;
-        if (iy < 0 || iy >= d.H) continue;                           // wave-uniform
-        float4 in[10];
+        const bool yok = iy >= 0 && iy < d.H;
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             const int ix = x0 - 1 + i;
-            in[i] = (ix >= 0 && ix < d.W) ? *reinterpret_cast<const float4*>(d.a + ((size_t)(b * d.H + iy) * d.W + ix) * d.ldx + 4 * lane)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = (yok && ix >= 0 && ix < d.W) ? (unsigned)(((b * d.H + iy) * d.W + ix) * d.ldx + 4 * lane) * 4u : ST_OOB;
+            in[ky][i] = buf_load16(rsrcA, off);
         }
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int p = 0; p < 8; ++p)
 #pragma unroll
                 for (int n = 0; n < NOUT; ++n) {
-                    const float4 xv = in[p + kx], w4 = wv[n][ky * 3 + kx];
+                    const float4 xv = in[ky][p + kx], w4 = wv[n][ky * 3 + kx];
                     float a = acc[p * NOUT + n];
                     a = fmaf(xv.x, w4.x, a); a = fmaf(xv.y, w4.y, a); a = fmaf(xv.z, w4.z, a); a = fmaf(xv.w, w4.w, a);
                     acc[p * NOUT + n] = a;
                 }
-    }
     // transposing butterfly: each step halves the number of values a lane carries; after log2(NV) steps lane l holds the
     // 64 / NV-lane partial sum of value v(l), v's bits taken from the lane bits used so far (high bits first)
     int cnt = NV / 2;
