@@ -209,12 +209,12 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-        float fx = 0.f, fy = 0.f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const size_t p2 = ((size_t)b * H + yy) * W + xx;
-            fx = 8.0f * (coords1[p2 * 2] - (float)xx);
-            fy = 8.0f * (coords1[p2 * 2 + 1] - (float)yy);
-        }
+        // (unconditional loads from a clamped address: the nine taps are in flight together)
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t p2 = ((size_t)b * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1);
+        const float2 cxy = *reinterpret_cast<const float2*>(coords1 + p2 * 2);
+        const float okf = ok ? 8.0f : 0.0f;                          // (a select on the loaded value would be turned back into a branch around the load)
+        const float fx = okf * (cxy.x - (float)xx), fy = okf * (cxy.y - (float)yy);
         const float wgt = mv[k] / sum;
         ox += wgt * fx; oy += wgt * fy;
     }

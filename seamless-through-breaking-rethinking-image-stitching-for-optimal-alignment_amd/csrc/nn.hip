@@ -198,10 +198,14 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ x, const float* __res
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
+            // unconditional loads (a padded tap reads a clamped address and is zeroed afterwards): all 18 are in flight together --
+            // behind a branch hipcc waited for each pair in turn, nine dependent round trips per thread
             const int iy = oy - 1 + a, ix = ox - 1 + e;
-            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-            const float4 xv = *reinterpret_cast<const float4*>(x + (((size_t)b * H + iy) * W + ix) * C + c);
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            float4 xv = *reinterpret_cast<const float4*>(x + (((size_t)b * H + cy) * W + cx) * C + c);
             const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)(a * 3 + e) * C + c);
+            if (!ok) xv = make_float4(0.f, 0.f, 0.f, 0.f);           // fma(0, w, acc) = acc: the same sum as skipping the tap
             acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
             acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
         }
@@ -779,11 +783,16 @@ __global__ __launch_bounds__(256) void ccl_softargmax_kernel(const float* __rest
         if (q < P) {
             const int qy = q / w, qx = q % w;
             s = 0.f;
+#pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int ay = py + dy, ax = px + dx, by = qy + dy, bx = qx + dx;
-                    if (ay >= 0 && ay < h && ax >= 0 && ax < w && by >= 0 && by < h && bx >= 0 && bx < w)
-                        s += Gb[(size_t)(ay * w + ax) * P + by * w + bx];
+                    const bool ok = ay >= 0 && ay < h && ax >= 0 && ax < w && by >= 0 && by < h && bx >= 0 && bx < w;
+                    // unconditional load from a clamped address, then the same ordered sum (s + 0 = s): the 9 taps of the 4 columns are
+                    // in flight together instead of 36 dependent round trips
+                    const float gv = Gb[(size_t)(min(max(ay, 0), h - 1) * w + min(max(ax, 0), w - 1)) * P + min(max(by, 0), h - 1) * w + min(max(bx, 0), w - 1)];
+                    s += ok ? gv : 0.f;
                 }
             s *= 10.0f;
         }
