@@ -241,11 +241,11 @@ extern "C" int st_convex_upsample(const float* coords1, const float* mask, int32
 //   q     = Wq . (LN1(query) + sinePE(coords1)) + bq
 //   x     = query + Wp . MHA(q; k, v of the pixel's 8 cost-memory tokens) + bp     (8 heads x 8)
 //   out   = x + Wf3 . gelu(Wf0 . LN2(x) + bf0) + bf3                      -> cost_global
-// Every step is row-local with 64 channels, so one wave carries a 16-row tile through all six
-// 64-wide products on v_mfma_f32_16x16x4_f32 without leaving the CU: weights sit in LDS once per
-// workgroup, the tile bounces through a per-wave LDS slab only to turn the MFMA C layout back into
-// an A operand.  Replaces 11 launches per iteration (2 GEMM + LN + PE + GEMM + attention + GEMM +
-// LN + 2 GEMM) that were each latency-bound at M = 4096..8192 rows.
+// Every step is row-local with 64 channels, so a 16-row tile goes through all six 64-wide products on
+// v_mfma_f32_16x16x4_f32 without leaving the CU (two waves per tile, see the kernel): weights sit in LDS once per
+// workgroup, the tile bounces through LDS slabs only to turn the MFMA C layout back into an A operand.
+// Replaces 11 launches per iteration (2 GEMM + LN + PE + GEMM + attention + GEMM + LN + 2 GEMM) that were each
+// latency-bound at M = 4096..8192 rows.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TC_LDW 68      // LDS row stride of a 64-wide weight / activation row (floats): conflict-free b128 reads
@@ -255,54 +255,66 @@ struct TokenChainArgs {
     const float *w0, *b0, *w2, *b2, *n1w, *n1b, *wq, *bq, *wp, *bp, *n2w, *n2b, *wf0, *bf0, *wf3, *bf3;
 };
 
-// acc[t] (16x16 tile t of the 16x64 result, C layout) = X[16 x K] . W[64 x K]^T ; K multiple of 16
-template <int K, int LDX, int LDWT>
-__device__ __forceinline__ void tc_gemm(const float* __restrict__ X, const float* __restrict__ Wl, f32x4 acc[4], int lane) {
-    const int i = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < K / 16; ++j) {
-        const float4 a = *reinterpret_cast<const float4*>(X + i * LDX + 16 * j + 4 * g);
-        float4 b[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const float4*>(Wl + (16 * t + i) * LDWT + 16 * j + 4 * g);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
-    }
-}
-
-// C layout -> row-major LDS slab: lane (c = lane&15, g = lane>>4) holds rows 4g..4g+3 of column 16t+c
-__device__ __forceinline__ void tc_store(float* __restrict__ X, const f32x4 v[4], int lane) {
-    const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X[(4 * g + r) * TC_LDW + 16 * t + c] = v[t][r];
-}
-
 __device__ __forceinline__ float sum16(float v) {     // across the 16 lanes that share lane>>4
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
     return v;
 }
 
-__device__ __forceinline__ void tc_layernorm(f32x4 v[4], const float* __restrict__ w, const float* __restrict__ b, int lane) {
-    const int c = lane & 15;
+// acc[t] (tile t of THIS wave's 16x32 column half, C layout) = X[16 x K] . Wh[32 x K]^T ; Wh = the 32 weight rows of the half
+template <int K, int LDX, int LDWT>
+__device__ __forceinline__ void tc_gemm2(const float* __restrict__ X, const float* __restrict__ Wh, f32x4 acc[2], int lane) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < K / 16; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(X + i * LDX + 16 * j + 4 * g);
+        float4 b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const float4*>(Wh + (16 * t + i) * LDWT + 16 * j + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+    }
+}
+
+// C layout -> the wave's 32 columns (starting at col0) of a row-major LDS slab with row stride TC_LDW
+__device__ __forceinline__ void tc_store2(float* __restrict__ X, const f32x4 v[2], int col0, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[(4 * g + r) * TC_LDW + col0 + 16 * t + c] = v[t][r];
+}
+
+// LayerNorm over the 64 columns of a row whose halves live in two waves: each wave reduces its 32 columns to (mean, sum of squared
+// deviations) exactly as a two-pass LayerNorm would, the two halves meet through `red` (one workgroup barrier) and are merged with the
+// pairwise update  M2 = M2_a + M2_b + (mean_a - mean_b)^2 * 32*32/64  -- no E[x^2] - mean^2 cancellation anywhere.
+__device__ __forceinline__ void tc_layernorm2(f32x4 v[2], const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ red_mine,
+                                              const float* __restrict__ red_other, int col0, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    float mh[4], m2h[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float mean = sum16((v[0][r] + v[1][r]) + (v[2][r] + v[3][r])) * (1.0f / 64.0f);
-        float q = 0.f;
+        mh[r] = sum16(v[0][r] + v[1][r]) * (1.0f / 32.0f);
+        const float d0 = v[0][r] - mh[r], d1 = v[1][r] - mh[r];
+        m2h[r] = sum16(d0 * d0 + d1 * d1);
+        if (c == 0) { red_mine[(4 * g + r) * 2] = mh[r]; red_mine[(4 * g + r) * 2 + 1] = m2h[r]; }
+    }
+    __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const float dlt = v[t][r] - mean; q += dlt * dlt; }
-        const float rstd = 1.0f / sqrtf(sum16(q) * (1.0f / 64.0f) + 1e-5f);
+    for (int r = 0; r < 4; ++r) {
+        const float mo = red_other[(4 * g + r) * 2], m2o = red_other[(4 * g + r) * 2 + 1];
+        const float mean = 0.5f * (mh[r] + mo), d = mh[r] - mo;
+        const float var = ((m2h[r] + m2o) + d * d * 16.0f) * (1.0f / 64.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t][r] = (v[t][r] - mean) * rstd * w[16 * t + c] + b[16 * t + c];
+        for (int t = 0; t < 2; ++t) v[t][r] = (v[t][r] - mean) * rstd * w[col0 + 16 * t + c] + b[col0 + 16 * t + c];
     }
 }
 
@@ -311,16 +323,19 @@ __device__ __forceinline__ void tc_static_for(F&& f) {       // literal indices:
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); tc_static_for<I + 1, N>(f); }
 }
 
-// Memory schedule: the kernel runs ONE wave per SIMD and has nothing to hide a memory round trip behind, so its global operands are
-// requested in two batches of unconditional loads (a row / token out of range reads a clamped address and is masked in the arithmetic:
-// hipcc turns `cond ? *p : 0` into load / s_waitcnt vmcnt(0) pairs, and the previous form of this kernel paid 40 dependent L2 round
-// trips -- tools/isa_waits.py): first the wave's 16 cost rows, its coords, the six weight matrices and the ten bias / LayerNorm vectors,
-// all staged into LDS; then, once those registers are free, the k AND v slices of its rows' memory tokens (64 float4 per lane, parked
-// in the register file the single wave owns), which land under the first three products.  After the one barrier the chain runs on
-// registers and LDS only; its single store is the result.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void decoder_token_chain_kernel(float* __restrict__ corr, int ldc, const float* __restrict__ coords1,
-                                                                     const float* __restrict__ kv, TokenChainArgs A, int rows, int ntok) {
+// Work split: a 16-row tile is carried by TWO waves, each owning 32 of the 64 columns of every product (two 16x16 MFMA tiles, half the
+// MFMAs, half the epilogue / GELU / sine arithmetic, 4 of the 8 attention heads): the chain is a serial sequence of short dependent
+// steps, one wave per SIMD, so its duration is the instruction count of ONE wave -- halving that count matters, MFMA utilisation does
+// not.  The halves meet in LDS: activations ping-pong between two slabs (S0 / S1) with one workgroup barrier per product, LayerNorm
+// statistics through `red`.  A workgroup = RG row tiles x 2 halves (29 -> 19.5 us stand-alone at 8192 rows with RG = 2).
+// Memory schedule: nothing hides a memory round trip here, so the global operands are requested in two batches of unconditional
+// loads (a row / token out of range reads a clamped address and is masked in the arithmetic: hipcc turns `cond ? *p : 0` into
+// load / s_waitcnt vmcnt(0) pairs -- an earlier form of this kernel paid 40 dependent L2 round trips, tools/isa_waits.py): first the
+// cost rows, coords, the six weight matrices and the ten bias / LayerNorm vectors, all staged into LDS; then, once those registers are
+// free, the k AND v slices of the wave's heads (32 float4 per lane), which land under the first three products.
+template <int RG>                                    // row tiles per workgroup (2 waves each)
+__global__ __launch_bounds__(128 * RG) void decoder_token_chain_kernel(float* __restrict__ corr, int ldc, const float* __restrict__ coords1,
+                                                                       const float* __restrict__ kv, TokenChainArgs A, int rows, int ntok) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* W0 = sm;                                  // [64][TC_LDW0]
     float* W2 = W0 + 64 * TC_LDW0;                   // five [64][TC_LDW]
@@ -329,29 +344,33 @@ __global__ __launch_bounds__(64 * NW) void decoder_token_chain_kernel(float* __r
     float* Wf0 = Wp + 64 * TC_LDW;
     float* Wf3 = Wf0 + 64 * TC_LDW;
     float* Vec = Wf3 + 64 * TC_LDW;                  // ten 64-float vectors: b0 b2 n1w n1b bq bp n2w n2b bf0 bf3
-    float* Xall = Vec + 10 * 64;                     // NW waves x [16][TC_LDW0]
+    float* Slab = Vec + 10 * 64;                     // RG row tiles x { S0 [16][TC_LDW0], S1 [16][TC_LDW] }
+    float* Red = Slab + RG * 16 * (TC_LDW0 + TC_LDW); // RG row tiles x 2 halves x 16 rows x (mean, M2)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NT = 64 * NW;                      // NW waves per workgroup, 16 rows each
-    float* X = Xall + wave * 16 * TC_LDW0;
-    const int row0 = (blockIdx.x * NW + wave) * 16;
+    constexpr int NT = 128 * RG;
+    const int rg = wave >> 1, hf = wave & 1, col0 = 32 * hf;
+    float* S0 = Slab + rg * 16 * (TC_LDW0 + TC_LDW);
+    float* S1 = S0 + 16 * TC_LDW0;
+    float* red_mine = Red + (rg * 2 + hf) * 32;
+    const float* red_other = Red + (rg * 2 + (hf ^ 1)) * 32;
+    const int row0 = (blockIdx.x * RG + rg) * 16;
     const int c = lane & 15, g = lane >> 4;
     const int jmax = ntok - 1;
 
     // ---- batch 1: cost rows, weights, vectors, coords
-    constexpr int P0 = 1536 / NT, P1 = 1024 / NT, NVEC = (160 + NT - 1) / NT;
-    float4 xv[6], w0v[P0];
-    f32x4 wv[5 * P1], vecv[NVEC];        // (first-class vectors: a float4 copied global -> array -> LDS stays a memcpy chain through the stack)
+    constexpr int P0 = 1536 / NT, P1 = 1024 / NT;
+    float4 xv[3], w0v[P0];
+    f32x4 wv[5 * P1], vecv;              // (first-class vectors: a float4 copied global -> array -> LDS stays a memcpy chain through the stack)
     float cx[4], cy[4];
-    tc_static_for<0, NVEC>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int e = min(tid + NT * i, 159), q = e >> 4;
+    {
+        const int e = min(tid, 159), q = e >> 4;
         const float* vp = q == 0 ? A.b0 : q == 1 ? A.b2 : q == 2 ? A.n1w : q == 3 ? A.n1b : q == 4 ? A.bq : q == 5 ? A.bp : q == 6 ? A.n2w
                           : q == 7 ? A.n2b : q == 8 ? A.bf0 : A.bf3;
-        vecv[i] = *reinterpret_cast<const f32x4*>(vp + 4 * (e & 15));
-    });
-    tc_static_for<0, 6>([&](auto ic) {               // 16 cost_forward rows (84 wide = 21 float4, zero padded to 96); rows are 16-B aligned
+        vecv = *reinterpret_cast<const f32x4*>(vp + 4 * (e & 15));
+    }
+    tc_static_for<0, 3>([&](auto ic) {               // 16 cost_forward rows (84 wide = 21 float4, zero padded to 96), half of them per wave
         constexpr int i = decltype(ic)::value;
-        const int e = lane + 64 * i, r = e / 24, k4 = e % 24;
+        const int e = (hf * 64 + lane) + 128 * i, r = e / 24, k4 = e % 24;
         xv[i] = *reinterpret_cast<const float4*>(corr + (size_t)min(row0 + r, rows - 1) * ldc + 4 * min(k4, 20));
     });
     tc_static_for<0, P0>([&](auto ic) {              // first layer: 64 x 24 float4 (84 real columns = 21, zero up to 96)
@@ -374,10 +393,10 @@ __global__ __launch_bounds__(64 * NW) void decoder_token_chain_kernel(float* __r
         cx[r] = p2.x; cy[r] = p2.y;
     }
     // ---- -> LDS
-    tc_static_for<0, 6>([&](auto ic) {
+    tc_static_for<0, 3>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const int e = lane + 64 * i, r = e / 24, k4 = e % 24;
-        *reinterpret_cast<float4*>(X + r * TC_LDW0 + 4 * k4) = k4 < 21 ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int e = (hf * 64 + lane) + 128 * i, r = e / 24, k4 = e % 24;
+        *reinterpret_cast<float4*>(S0 + r * TC_LDW0 + 4 * k4) = k4 < 21 ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     });
     tc_static_for<0, P0>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -393,142 +412,124 @@ __global__ __launch_bounds__(64 * NW) void decoder_token_chain_kernel(float* __r
         *reinterpret_cast<f32x4*>(Wf0 + off) = wv[5 * i + 3];
         *reinterpret_cast<f32x4*>(Wf3 + off) = wv[5 * i + 4];
     });
-    tc_static_for<0, NVEC>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int e = tid + NT * i;
-        if (e < 160) *reinterpret_cast<f32x4*>(Vec + 4 * e) = vecv[i];
-    });
-    // ---- batch 2: lane (row = lane & 15, quarter g) owns columns 16g .. 16g+15 = two heads of its row: that slice of the row's k / v
-    // tokens, first read three products later
+    if (tid < 160) *reinterpret_cast<f32x4*>(Vec + 4 * tid) = vecv;
+    // ---- batch 2: lane (row = lane & 15, e = lane >> 4) owns head 4 hf + e of its row (columns 8 head .. +7): that slice of the row's
+    // k / v tokens, first read three products later
     asm volatile("" ::: "memory");
-    float4 kk[8][4], vv[8][4];
+    const int head = 4 * hf + g;
+    float4 kk[8][2], vv[8][2];
     {
-        const float* kvr = kv + (size_t)min(row0 + c, rows - 1) * ntok * 128 + 16 * g;
+        const float* kvr = kv + (size_t)min(row0 + c, rows - 1) * ntok * 128 + 8 * head;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) kk[j][e] = *reinterpret_cast<const float4*>(kvr + min(j, jmax) * 128 + 4 * e);
+            for (int e = 0; e < 2; ++e) kk[j][e] = *reinterpret_cast<const float4*>(kvr + min(j, jmax) * 128 + 4 * e);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vv[j][e] = *reinterpret_cast<const float4*>(kvr + min(j, jmax) * 128 + 64 + 4 * e);
+            for (int e = 0; e < 2; ++e) vv[j][e] = *reinterpret_cast<const float4*>(kvr + min(j, jmax) * 128 + 64 + 4 * e);
     }
     asm volatile("" ::: "memory");
     __syncthreads();
     const float *b0 = Vec, *b2 = Vec + 64, *n1w = Vec + 128, *n1b = Vec + 192, *bq = Vec + 256, *bp = Vec + 320, *n2w = Vec + 384,
                 *n2b = Vec + 448, *bf0 = Vec + 512, *bf3 = Vec + 576;
-    f32x4 acc[4], query[4], x[4];
+    f32x4 acc[2], query[2], x[2];
     // ---- flow_token_encoder
-    tc_gemm<96, TC_LDW0, TC_LDW0>(X, W0, acc, lane);
+    tc_gemm2<96, TC_LDW0, TC_LDW0>(S0, W0 + col0 * TC_LDW0, acc, lane);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + b0[16 * t + c], ST_ACT_GELU);
-    __builtin_amdgcn_wave_barrier();
-    tc_store(X, acc, lane);
-    __builtin_amdgcn_wave_barrier();
-    tc_gemm<64, TC_LDW, TC_LDW>(X, W2, query, lane);
+        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + b0[col0 + 16 * t + c], ST_ACT_GELU);
+    tc_store2(S1, acc, col0, lane);
+    __syncthreads();
+    tc_gemm2<64, TC_LDW, TC_LDW>(S1, W2 + col0 * TC_LDW, query, lane);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) query[t][r] += b2[16 * t + c];
-    // ---- LN1 + sine PE of coords1 (tile t = sin x | cos x | sin y | cos y, band = c)
+        for (int r = 0; r < 4; ++r) query[t][r] += b2[col0 + 16 * t + c];
+    // ---- LN1 + sine PE of coords1 (columns: sin x | cos x | sin y | cos y, 16 each, band = c: this wave has x (hf = 0) or y)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = query[t];
-    tc_layernorm(acc, n1w, n1b, lane);
+    for (int t = 0; t < 2; ++t) acc[t] = query[t];
+    tc_layernorm2(acc, n1w, n1b, red_mine, red_other, col0, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float ax = ((3.14f * cx[r]) * (float)c) * 0.005f, ay = ((3.14f * cy[r]) * (float)c) * 0.005f;
-        acc[0][r] += sinf(ax); acc[1][r] += cosf(ax); acc[2][r] += sinf(ay); acc[3][r] += cosf(ay);
+        const float a = ((3.14f * (hf ? cy[r] : cx[r])) * (float)c) * 0.005f;
+        acc[0][r] += sinf(a); acc[1][r] += cosf(a);
     }
-    __builtin_amdgcn_wave_barrier();
-    tc_store(X, acc, lane);
-    __builtin_amdgcn_wave_barrier();
-    tc_gemm<64, TC_LDW, TC_LDW>(X, Wq, acc, lane);                       // q
-    // ---- 8-head attention over the pixel's ntok memory tokens (head = column / 8), in ROW layout: q goes back
-    // to the slab, then lane (row = lane&15, quarter = lane>>4) owns columns 16*quarter..+15 = two heads of its row
-    // (no cross-lane traffic at all).
+    tc_store2(S0, acc, col0, lane);                  // S0 as a [16][TC_LDW] slab from here on
+    __syncthreads();
+    tc_gemm2<64, TC_LDW, TC_LDW>(S0, Wq + col0 * TC_LDW, acc, lane);     // q: the wave's 32 columns = its own 4 heads
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] += bq[16 * t + c];
-    __builtin_amdgcn_wave_barrier();
-    tc_store(X, acc, lane);
+        for (int r = 0; r < 4; ++r) acc[t][r] += bq[col0 + 16 * t + c];
+    // ---- 8-head attention over the pixel's ntok memory tokens (head = column / 8), in ROW layout: the wave's q columns go to the
+    // slab (its own columns: a wave barrier is enough), lane (row, e) reads head 4 hf + e of its row, k / v come from registers
+    tc_store2(S1, acc, col0, lane);
     __builtin_amdgcn_wave_barrier();
     {
         const float scale = 0.35355339059327373f;                         // 8^-0.5
-        const int arow = lane & 15;
-        float qv[16], o[16];
-#pragma unroll
-        for (int e = 0; e < 16; e += 4) {
-            const float4 t4 = *reinterpret_cast<const float4*>(X + arow * TC_LDW + 16 * g + e);
-            qv[e] = t4.x; qv[e + 1] = t4.y; qv[e + 2] = t4.z; qv[e + 3] = t4.w;
+        float qv[8], o[8];
+        {
+            const float4 t0 = *reinterpret_cast<const float4*>(S1 + c * TC_LDW + 8 * head);
+            const float4 t1 = *reinterpret_cast<const float4*>(S1 + c * TC_LDW + 8 * head + 4);
+            qv[0] = t0.x; qv[1] = t0.y; qv[2] = t0.z; qv[3] = t0.w; qv[4] = t1.x; qv[5] = t1.y; qv[6] = t1.z; qv[7] = t1.w;
         }
-        float s0[8], s1[8];
+        float s0[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float a0 = 0.f, a1 = 0.f;
-            float kf[16];
+            float a0 = 0.f;
+            const float kf[8] = {kk[j][0].x, kk[j][0].y, kk[j][0].z, kk[j][0].w, kk[j][1].x, kk[j][1].y, kk[j][1].z, kk[j][1].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { kf[4 * e] = kk[j][e].x; kf[4 * e + 1] = kk[j][e].y; kf[4 * e + 2] = kk[j][e].z; kf[4 * e + 3] = kk[j][e].w; }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { a0 = fmaf(qv[e], kf[e], a0); a1 = fmaf(qv[8 + e], kf[8 + e], a1); }
+            for (int e = 0; e < 8; ++e) a0 = fmaf(qv[e], kf[e], a0);
             s0[j] = j < ntok ? a0 * scale : -INFINITY;
-            s1[j] = j < ntok ? a1 * scale : -INFINITY;
         }
-        float m0 = s0[0], m1 = s1[0];
+        float m0 = s0[0];
 #pragma unroll
-        for (int j = 1; j < 8; ++j) { m0 = fmaxf(m0, s0[j]); m1 = fmaxf(m1, s1[j]); }
-        float d0 = 0.f, d1 = 0.f;
+        for (int j = 1; j < 8; ++j) m0 = fmaxf(m0, s0[j]);
+        float d0 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             // (a token past ntok has s = -inf: p = exp(-inf) = 0 exactly, and its clamped v adds +0)
-            const float p0 = expf(s0[j] - m0), p1 = expf(s1[j] - m1);
-            d0 += p0; d1 += p1;
+            const float p0 = expf(s0[j] - m0);
+            d0 += p0;
+            const float vf[8] = {vv[j][0].x, vv[j][0].y, vv[j][0].z, vv[j][0].w, vv[j][1].x, vv[j][1].y, vv[j][1].z, vv[j][1].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float4 t4 = vv[j][e];
-                const float pe = e < 2 ? p0 : p1;
-                o[4 * e] = fmaf(pe, t4.x, o[4 * e]); o[4 * e + 1] = fmaf(pe, t4.y, o[4 * e + 1]);
-                o[4 * e + 2] = fmaf(pe, t4.z, o[4 * e + 2]); o[4 * e + 3] = fmaf(pe, t4.w, o[4 * e + 3]);
-            }
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(p0, vf[e], o[e]);
         }
-        const float i0 = 1.0f / d0, i1 = 1.0f / d1;
-#pragma unroll
-        for (int e = 0; e < 16; e += 4)
-            *reinterpret_cast<float4*>(X + arow * TC_LDW + 16 * g + e) =
-                make_float4(o[e] * (e < 8 ? i0 : i1), o[e + 1] * (e < 8 ? i0 : i1), o[e + 2] * (e < 8 ? i0 : i1), o[e + 3] * (e < 8 ? i0 : i1));
+        const float i0 = 1.0f / d0;
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<float4*>(S1 + c * TC_LDW + 8 * head) = make_float4(o[0] * i0, o[1] * i0, o[2] * i0, o[3] * i0);
+        *reinterpret_cast<float4*>(S1 + c * TC_LDW + 8 * head + 4) = make_float4(o[4] * i0, o[5] * i0, o[6] * i0, o[7] * i0);
     }
-    __builtin_amdgcn_wave_barrier();
-    tc_gemm<64, TC_LDW, TC_LDW>(X, Wp, acc, lane);
+    __syncthreads();
+    tc_gemm2<64, TC_LDW, TC_LDW>(S1, Wp + col0 * TC_LDW, acc, lane);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[t][r] = query[t][r] + (acc[t][r] + bp[16 * t + c]);     // short_cut + proj
+        for (int r = 0; r < 4; ++r) x[t][r] = query[t][r] + (acc[t][r] + bp[col0 + 16 * t + c]);     // short_cut + proj
     // ---- FFN
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = x[t];
-    tc_layernorm(acc, n2w, n2b, lane);
-    __builtin_amdgcn_wave_barrier();
-    tc_store(X, acc, lane);
-    __builtin_amdgcn_wave_barrier();
-    tc_gemm<64, TC_LDW, TC_LDW>(X, Wf0, acc, lane);
+    for (int t = 0; t < 2; ++t) acc[t] = x[t];
+    tc_layernorm2(acc, n2w, n2b, red_mine, red_other, col0, lane);
+    tc_store2(S0, acc, col0, lane);
+    __syncthreads();
+    tc_gemm2<64, TC_LDW, TC_LDW>(S0, Wf0 + col0 * TC_LDW, acc, lane);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + bf0[16 * t + c], ST_ACT_GELU);
-    __builtin_amdgcn_wave_barrier();
-    tc_store(X, acc, lane);
-    __builtin_amdgcn_wave_barrier();
-    tc_gemm<64, TC_LDW, TC_LDW>(X, Wf3, acc, lane);
+        for (int r = 0; r < 4; ++r) acc[t][r] = st_act(acc[t][r] + bf0[col0 + 16 * t + c], ST_ACT_GELU);
+    tc_store2(S1, acc, col0, lane);
+    __syncthreads();
+    tc_gemm2<64, TC_LDW, TC_LDW>(S1, Wf3 + col0 * TC_LDW, acc, lane);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row0 + 4 * g + r;
-            if (row < rows) corr[(size_t)row * ldc + 84 + 16 * t + c] = x[t][r] + (acc[t][r] + bf3[16 * t + c]);
+            if (row < rows) corr[(size_t)row * ldc + 84 + col0 + 16 * t + c] = x[t][r] + (acc[t][r] + bf3[col0 + 16 * t + c]);
         }
 }
 
@@ -538,12 +539,13 @@ extern "C" int st_decoder_token_chain(float* corr, int32_t ld_corr, const float*
     TokenChainArgs A;
     const float** dst = reinterpret_cast<const float**>(&A);
     for (int i = 0; i < 16; ++i) { if (!weights16[i]) return ST_EINVAL; dst[i] = weights16[i]; }
-    // 4 waves (64 rows) per workgroup: 128 workgroups at 8192 rows -- the kernel holds 128 KB of LDS, so it keeps the CUs it runs on
-    // to itself; on half the chip it leaves the other half to the GEMM workgroups of the other pairs in flight
-    constexpr int NW = 4;
-    const size_t lds = (size_t)(64 * TC_LDW0 + 5 * 64 * TC_LDW + 640 + NW * 16 * TC_LDW0) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)decoder_token_chain_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(decoder_token_chain_kernel<NW>, dim3((rows + 16 * NW - 1) / (16 * NW)), dim3(64 * NW), lds, (hipStream_t)stream, corr, ld_corr,
+    // 4 row tiles (8 waves, 64 rows) per workgroup: the kernel holds 156 KB of LDS and keeps the CUs it runs on to itself, so it should
+    // hold as few CU-microseconds as possible: 128 workgroups x ~24 us (two waves per SIMD) against 256 x 19.5 us with 2 row tiles --
+    // measured with three pairs in flight: 81.4 vs 81.2 pairs/s (one pair in flight: 71.8 vs 72.1)
+    constexpr int RG = 4;
+    const size_t lds = (size_t)(64 * TC_LDW0 + 5 * 64 * TC_LDW + 640 + RG * 16 * (TC_LDW0 + TC_LDW) + RG * 64) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)decoder_token_chain_kernel<RG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(decoder_token_chain_kernel<RG>, dim3((rows + 16 * RG - 1) / (16 * RG)), dim3(128 * RG), lds, (hipStream_t)stream, corr, ld_corr,
                        coords1, kv, A, rows, ntok);
     ST_CHECK_LAUNCH();
     return ST_OK;

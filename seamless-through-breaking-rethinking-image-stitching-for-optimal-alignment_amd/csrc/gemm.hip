@@ -686,7 +686,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
     // (rms 5.7e-7 vs 3.4e-7 at K = 1024, 8.6e-7 vs 3.1e-7 at K = 2304; profiles/r2_parity_trace_*.txt).  So the chain is
     // cut every KBLK K steps (256 k): the running tile is folded into `tot` and restarted from zero.  16 v_add per
     // 32x32 sub-tile every 128 MFMAs; K <= 256 never folds.
-    constexpr int KBLK = 2 * STAGES;
+    constexpr int KBLK = 8;                         // K steps per block (256 k), whatever the ring depth
     f32x16 tot[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -793,6 +793,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
             // ---- k-step 3 (buffer 1); step 0 of the next tile is read under it (a stale read after the last tile)
             mfma_k(1, 0); ST_GAP(read_frags(0, nstage, 0));
             mfma_k(1, 1); mfma_k(1, 2); mfma_k(1, 3);
+            if (STAGES != 4 && (t & (KBLK - 1)) == KBLK - 1 && t + 1 < ntiles) fold();    // (4-deep ring: folded by the callers, at block ends)
         };
         if (PERSIST) {
             for (int mt = 0; mt < nmt; ++mt) {
@@ -822,13 +823,13 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
             for (; tb + 2 * STAGES - 1 <= ntiles; tb += STAGES) {       // every tile of the block still feeds a new one
 #pragma unroll
                 for (int s = 0; s < STAGES; ++s) tile_body(st_true{}, s, tb + s);
-                if ((tb + STAGES) % KBLK == 0) fold();
+                if (STAGES == 4 && (tb + STAGES) % KBLK == 0) fold();
             }
             for (; tb < ntiles; tb += STAGES) {
 #pragma unroll
                 for (int s = 0; s < STAGES; ++s)
                     if (tb + s < ntiles) tile_body(st_false{}, s, tb + s);
-                if ((tb + STAGES) % KBLK == 0 && tb + STAGES < ntiles) fold();
+                if (STAGES == 4 && (tb + STAGES) % KBLK == 0 && tb + STAGES < ntiles) fold();
             }
             if (ntiles > KBLK) unfold();
         }
@@ -1389,7 +1390,7 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
     const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M &&
                        d.Ho * d.Wo == d.M;
     const int slots = 512 / batch;
-    if (plain && !d.a2 && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
+    if (STAGES == 4 && plain && !d.a2 && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
         int G = slots / ntn;
         if (G > ntm) G = ntm;
         auto k = d.c_t ? conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true, true> : conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true>;
@@ -1594,6 +1595,9 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     d.split_k = split;
     g_last_plan[0] = cfg > 10 ? 3 : 2; g_last_plan[1] = cfg; g_last_plan[2] = split; g_last_plan[3] = 0;
     if (cfg == 12) return launch_dma<2, 2, 2, 1, 4>(d, s);
+    // (a 3-deep ring -- 48 KB, three workgroups per CU -- is correct with this body (the K-block fold is independent of the ring depth) and
+    // was measured: kernels of different pairs overlap better (3-in-flight / 1-in-flight 1.18 instead of 1.135) but a tile then has ONE K
+    // step to land and every kernel slows down: 71.9 -> 67.9 pairs/s with one pair in flight, 81.6 -> 80.2 with three)
     if (cfg == 13) return launch_dma<2, 2, 1, 1, 4>(d, s);
     if (cfg == 14) return launch_dma<4, 1, 1, 1, 4>(d, s);
     switch (cfg) {
