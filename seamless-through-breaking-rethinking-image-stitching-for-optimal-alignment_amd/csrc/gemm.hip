@@ -1599,7 +1599,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     // was measured: kernels of different pairs overlap better (3-in-flight / 1-in-flight 1.18 instead of 1.135) but a tile then has ONE K
     // step to land and every kernel slows down: 71.9 -> 67.9 pairs/s with one pair in flight, 81.6 -> 80.2 with three)
     if (cfg == 13) return launch_dma<2, 2, 1, 1, 4>(d, s);
-    if (cfg == 14) return launch_dma<4, 1, 1, 1, 4>(d, s);
+    if (cfg == 14) return launch_dma<4, 1, 1, 1, 4>(d, s);      // (80 KB of LDS; a 3-deep ring, 60 KB, measured neutral: PatchEmbed's 6x3 conv is not occupancy-bound)
     switch (cfg) {
         case 1: return launch_cfg<2, 2, 2, 2>(d, aligned, s);
         case 2: return launch_cfg<2, 2, 2, 1>(d, aligned, s);
