@@ -11,6 +11,8 @@ tot = 0.0
 gemm = 0.0
 print(f"forwards: {fw}")
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+    if "spin_kernel" in r["Name"]:      # torch.cuda._sleep of bench.py's instrumented step: not part of a forward
+        continue
     ms = float(r["TotalDurationNs"]) / fw / 1e6
     tot += ms
     if any(k in r["Name"] for k in ("conv_gemm", "rowstream_gemm", "rowchain128", "splitk_reduce", "narrow_conv", "skinny_gemm")):
@@ -21,5 +23,6 @@ print(f"total kernel time per forward {tot:.3f} ms; GEMM family {gemm:.3f} ms; o
 if len(sys.argv) > 3:          # python tools/kernel_stats_summary.py STATS.csv FORWARDS OUT.json
     import json
     json.dump(dict(forwards=fw, total_kernel_ms_per_forward=tot, gemm_family_ms_per_forward=gemm, other_kernels_ms_per_forward=tot - gemm,
-                   source="rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-corr-roofline (3 pairs in flight; "
-                          "kernels of different pairs overlap, so per-kernel durations include contention)"), open(sys.argv[3], "w"), indent=1)
+                   source="rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-corr-roofline (kernel tracing serialises "
+                          "the dispatches of the three streams -- tools/trace_overlap.py on the same trace: one kernel resident 78 % of the time, "
+                          "two 0.6 % -- so these are STAND-ALONE kernel durations; the timed region runs them overlapped)"), open(sys.argv[3], "w"), indent=1)
