@@ -4,7 +4,8 @@
     python tools/gemm_shapes_csv.py OUT.csv [--launches LAUNCHES.json]           # timing pass (HIP events, observer hook)
     python tools/gemm_shapes_csv.py OUT.csv --join LAUNCHES.json FETCH.csv WRITE.csv   # add PMC bytes per shape (no GPU)
 
-Timing pass: two warm-up steps, then one eager step with a HIP-event pair around every launch (library observer,
+Timing pass: two warm-up steps, then one eager step (enqueued behind a spin kernel; the median reading of an empty event bracket is
+subtracted) with a HIP-event pair around every launch (library observer,
 `st_gemm_last_plan` tells which kernel / tile / split-K / persistent walk the library chose).  With --launches the ordered
 launch list is saved so that a later `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` run OF THE SAME
 COMMAND (one counter per pass, MI355X_MICROARCH.md) can be joined: GEMM-family dispatches appear in the same order in
@@ -63,23 +64,58 @@ def timing_pass(out_csv, launches_json=None, profile_only=False):
                         ev=(open_ev.pop(), ev)))
 
     lib.st_set_gemm_observer(C.cast(observer, C.c_void_p), None)
+    empties = []
     try:
+        if not profile_only:
+            # hold the stream back (~0.1 s spin kernel) while the host enqueues the eager step, as bench.py's instrumented step does: a
+            # bracket then reads its kernel(s) + the event overhead, not the Python launch latency an idle GPU would wait for (without
+            # it the first launches of the step read ~100 us whatever they do)
+            torch.cuda._sleep(int(2.4e8))
         model(a, b, type="test_eval")
+        if not profile_only:
+            st = torch.cuda.current_stream()
+            for _ in range(64):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st); e1.record(st)
+                empties.append((e0, e1))
         torch.cuda.synchronize()
     finally:
         lib.st_set_gemm_observer(None, None)
+    ov = sorted(e0.elapsed_time(e1) for e0, e1 in empties)[len(empties) // 2] if empties else 0.0     # an EMPTY bracket's reading (ms)
     for r in rec:
         e0, e1 = r.pop("ev")
-        r["us"] = 1e3 * e0.elapsed_time(e1) if e0 is not None else 0.0
+        r["us"] = 1e3 * max(0.0, e0.elapsed_time(e1) - ov) if e0 is not None else 0.0
     if launches_json:
         json.dump(rec, open(launches_json, "w"))
     if not profile_only:
         write_csv(out_csv, rec)
 
 
+def merge_pairs(rec):
+    """st_conv_gemm_pair: the observer reports the first member with an empty bracket (persist = 2) and the second (persist = 3) with the
+    pair's single dispatch and all of its time: one row for the launch, N = 'N0+N1', K of the first member, FLOPs and bytes summed."""
+    out, i = [], 0
+    while i < len(rec):
+        r = rec[i]
+        if r["persist"] == 2 and i + 1 < len(rec) and rec[i + 1]["persist"] == 3:
+            m = dict(r)
+            o = rec[i + 1]
+            m.update(N=f"{r['N']}+{o['N']}", kernel="conv_gemm_dma_pair_kernel", persist=0, us=r["us"] + o["us"], flops=r["flops"] + o["flops"],
+                     alg_bytes=r["alg_bytes"] + o["alg_bytes"])
+            if "fetch_bytes" in o:
+                m["fetch_bytes"] = r.get("fetch_bytes", 0.0) + o["fetch_bytes"]
+                m["write_bytes"] = r.get("write_bytes", 0.0) + o["write_bytes"]
+            out.append(m)
+            i += 2
+        else:
+            out.append(r)
+            i += 1
+    return out
+
+
 def write_csv(out_csv, rec):
     agg = collections.OrderedDict()
-    for r in rec:
+    for r in merge_pairs(rec):
         g = agg.setdefault(shape_key(r), dict(launches=0, us=0.0, flops=0.0, alg=0.0, fetch=0.0, write=0.0, pmc=0))
         g["launches"] += 1
         g["us"] += r["us"]
