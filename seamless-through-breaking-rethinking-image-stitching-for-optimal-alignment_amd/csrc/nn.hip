@@ -671,6 +671,11 @@ extern "C" int st_attention_kvlds(const float* q, int64_t q_bs, int64_t q_ts, co
 // q/k/v lives at base + b*bs + (y*W + x)*ts + h*D.  The grid is zero-padded to a multiple of ws
 // *before* the q/k/v projections in the reference, so a padded token's q/k/v is a constant per
 // window position: tables qpad/kpad/vpad [ws*ws, heads*D].  One wave per (window, head).
+// On the matrix cores, like attention_kv_mfma_kernel: a wave owns one (window, head); the window's ws*ws <= 64 tokens are its keys
+// AND its queries.  K / V rows are staged once into a per-wave [64][D+4] slab (lane = token; rows past ws*ws hold finite filler and
+// their scores are masked to -inf, so their probabilities are exactly 0), then four 16-query tiles run S^T = K . Q^T (16x16x4 MFMA,
+// the query in the lane's column), a register-local softmax in the log2 domain and O^T = V^T . P^T.  The VALU form of this kernel
+// issued ~45 instructions per (query, key) pair group on the datapath the MFMA shares (26 of its 34 us at 65 536 tokens x 8 heads).
 template <int D>
 __global__ __launch_bounds__(256) void window_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, long bs, long ts,
@@ -678,6 +683,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
                                                                const float* __restrict__ vpad, float* __restrict__ out,
                                                                long o_bs, long o_ts, int H, int W, int heads, int ws,
                                                                float scale) {
+    constexpr int LD = D + 4, DS = D / 4, DB = D / 16;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nww = (W + ws - 1) / ws;
@@ -686,64 +692,107 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
     if (h >= heads) return;                                    // whole wave exits together
     const int wy = win / nww, wx = win % nww;
     const int T = ws * ws, C = heads * D;
-    float* Ks = sm + (size_t)wave * 2 * T * D;
-    float* Vs = Ks + (size_t)T * D;
-    const int ty = lane / ws, tx = lane % ws;
-    const int y = wy * ws + ty, x = wx * ws + tx;
-    const bool tok = lane < T;
-    const bool inb = tok && y < H && x < W;
-    float qr[D];
-    if (tok) {
-        const float* qp = inb ? q + b * bs + ((long)y * W + x) * ts + h * D : qpad + (size_t)lane * C + h * D;
-        const float* kp = inb ? k + b * bs + ((long)y * W + x) * ts + h * D : kpad + (size_t)lane * C + h * D;
-        const float* vp = inb ? v + b * bs + ((long)y * W + x) * ts + h * D : vpad + (size_t)lane * C + h * D;
+    float* Ks = sm + (size_t)wave * 2 * 64 * LD;
+    float* Vs = Ks + 64 * LD;
+    // token t of the window -> its q / k / v row: the image token, or the pad table row of its window position (twins.py:587-600)
+    auto row_of = [&](const float* base, const float* pad, int t) {
+        const int tt = t < T ? t : 0;                             // (filler rows read token 0: finite, masked below)
+        const int ty = tt / ws, tx = tt - ty * ws;
+        const int y = wy * ws + ty, x = wx * ws + tx;
+        return (y < H && x < W) ? base + b * bs + ((long)y * W + x) * ts + h * D : pad + (size_t)tt * C + h * D;
+    };
+    {
+        // staging: D/4 consecutive lanes fetch the D/4 16-byte pieces of one token's row, so an instruction touches 64 / (D/4) rows of
+        // D*4 contiguous bytes (lane = token would touch 64 rows of 16 bytes each: four times the cache-line requests)
+        constexpr int PPT = D / 4, TPI = 64 / PPT;              // pieces per token, tokens per instruction
+        const int piece = lane % PPT, tl = lane / PPT;
+        float4 kr[PPT], vr[PPT];
 #pragma unroll
-        for (int e = 0; e < D; e += 4) {
-            const float4 a = *reinterpret_cast<const float4*>(qp + e);
-            qr[e] = a.x; qr[e + 1] = a.y; qr[e + 2] = a.z; qr[e + 3] = a.w;
-            *reinterpret_cast<float4*>(Ks + lane * D + e) = *reinterpret_cast<const float4*>(kp + e);
-            *reinterpret_cast<float4*>(Vs + lane * D + e) = *reinterpret_cast<const float4*>(vp + e);
+        for (int i = 0; i < PPT; ++i) {
+            const int t = i * TPI + tl;
+            kr[i] = *reinterpret_cast<const float4*>(row_of(k, kpad, t) + 4 * piece);
+            vr[i] = *reinterpret_cast<const float4*>(row_of(v, vpad, t) + 4 * piece);
+        }
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int t = i * TPI + tl;
+            *reinterpret_cast<float4*>(Ks + t * LD + 4 * piece) = kr[i];
+            *reinterpret_cast<float4*>(Vs + t * LD + 4 * piece) = vr[i];
+        }
+    }
+    const int c = lane & 15, g = lane >> 4;
+    // the four query tiles' fragments are requested before the slab is read (one memory round trip for the whole wave)
+    float qf[4][DS];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float* qp = row_of(q, qpad, 16 * t + c) + g * DS;
+        const float sl = scale * 1.44269504088896340736f;        // scores in the log2 domain: the softmax is a bare v_exp_f32
+#pragma unroll
+        for (int e = 0; e < DS; e += 4) {
+            const float4 tq = *reinterpret_cast<const float4*>(qp + e);
+            qf[t][e] = tq.x * sl; qf[t][e + 1] = tq.y * sl; qf[t][e + 2] = tq.z * sl; qf[t][e + 3] = tq.w * sl;
         }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes visible to its own lanes
-    if (!inb) return;
-    // one pass over the window's keys with a running maximum (scores are computed once; a new maximum rescales the
-    // running sum and accumulator -- rare after the first few keys)
-    float mx = -INFINITY;
-    float acc[D];
+    const float* Kl = Ks + c * LD + g * DS;         // + 16*kt*LD: this lane's K fragment (DS consecutive dims)
+    const float* Vl = Vs + (4 * g) * LD + c;        // + (16*kt + s)*LD (+16 for the second d block)
 #pragma unroll
-    for (int e = 0; e < D; ++e) acc[e] = 0.f;
-    float sum = 0.f;
-    for (int j = 0; j < T; ++j) {
-        float s = 0.f;
+    for (int t = 0; t < 4; ++t) {
+        if (16 * t >= T) break;                     // wave-uniform
+        kv_f32x4 sc[4];
+        float mx = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < D; e += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(Ks + j * D + e);
-            s = fmaf(qr[e], t.x, s); s = fmaf(qr[e + 1], t.y, s); s = fmaf(qr[e + 2], t.z, s); s = fmaf(qr[e + 3], t.w, s);
+        for (int kt = 0; kt < 4; ++kt) {
+            float kf[DS];
+#pragma unroll
+            for (int e = 0; e < DS; e += 4) {
+                const float4 tk = *reinterpret_cast<const float4*>(Kl + kt * 16 * LD + e);
+                kf[e] = tk.x; kf[e + 1] = tk.y; kf[e + 2] = tk.z; kf[e + 3] = tk.w;
+            }
+            kv_f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < DS; ++e) a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[t][e], a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = (16 * kt + 4 * g + r) < T ? a[r] : -INFINITY;     // keys past the window
+            sc[kt] = a;
+            mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
         }
-        s *= scale;
-        if (s > mx) {
-            const float r = __expf(mx - s);                       // exp(-inf) = 0 on the first key
-            sum *= r;
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+        kv_f32x4 o[DB], o2[DB];                     // two accumulation chains (keys r even / odd), folded at the end
 #pragma unroll
-            for (int e = 0; e < D; ++e) acc[e] *= r;
-            mx = s;
+        for (int db = 0; db < DB; ++db) { o[db] = kv_f32x4{0.f, 0.f, 0.f, 0.f}; o2[db] = kv_f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            kv_f32x4 p;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[kt][r] - mx); sum += p[r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    if (r & 1) o2[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vl[(kt * 16 + r) * LD + 16 * db], p[r], o2[db], 0, 0, 0);
+                    else o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vl[(kt * 16 + r) * LD + 16 * db], p[r], o[db], 0, 0, 0);
+                }
+            }
         }
-        const float p = __expf(s - mx);
-        sum += p;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
 #pragma unroll
-        for (int e = 0; e < D; e += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(Vs + j * D + e);
-            acc[e] = fmaf(p, t.x, acc[e]); acc[e + 1] = fmaf(p, t.y, acc[e + 1]);
-            acc[e + 2] = fmaf(p, t.z, acc[e + 2]); acc[e + 3] = fmaf(p, t.w, acc[e + 3]);
+        for (int db = 0; db < DB; ++db) o[db] += o2[db];
+        const int tq = 16 * t + c;
+        const int ty = tq / ws, tx = tq - ty * ws;
+        const int y = wy * ws + ty, x = wx * ws + tx;
+        if (tq < T && y < H && x < W) {
+            float* op = out + b * o_bs + ((long)y * W + x) * o_ts + h * D + 4 * g;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+                *reinterpret_cast<float4*>(op + 16 * db) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
         }
     }
-    const float inv = 1.0f / sum;
-    float* op = out + b * o_bs + ((long)y * W + x) * o_ts + h * D;
-#pragma unroll
-    for (int e = 0; e < D; e += 4)
-        *reinterpret_cast<float4*>(op + e) = make_float4(acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv);
 }
 
 extern "C" int st_window_attention(const float* q, const float* k, const float* v, int64_t bs, int64_t ts, const float* qpad,
@@ -752,10 +801,15 @@ extern "C" int st_window_attention(const float* q, const float* k, const float* 
     if (!q || !k || !v || !qpad || !kpad || !vpad || !out || ws * ws > 64 || ws <= 0) return ST_EINVAL;
     const int nwh = (H + ws - 1) / ws, nww = (W + ws - 1) / ws;
     dim3 grid(nwh * nww, (heads + 3) / 4, B), block(256);
-    const size_t lds = (size_t)4 * 2 * ws * ws * D * sizeof(float);
+    const size_t lds = (size_t)4 * 2 * 64 * (D + 4) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_WA(DD) hipLaunchKernelGGL(window_attention_kernel<DD>, grid, block, lds, s, q, k, v, bs, ts, qpad, kpad, vpad, \
-                                         out, o_bs, o_ts, H, W, heads, ws, scale)
+#define LAUNCH_WA(DD)                                                                                                       \
+    do {                                                                                                                    \
+        if (lds > 48 * 1024)                                                                                                \
+            (void)hipFuncSetAttribute((const void*)window_attention_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(window_attention_kernel<DD>, grid, block, lds, s, q, k, v, bs, ts, qpad, kpad, vpad, out, o_bs, o_ts, H, W, \
+                           heads, ws, scale);                                                                               \
+    } while (0)
     if (D == 16) LAUNCH_WA(16); else if (D == 32) LAUNCH_WA(32); else return ST_EINVAL;
 #undef LAUNCH_WA
     ST_CHECK_LAUNCH();
