@@ -437,8 +437,8 @@ class FlowFormer(ParamTree):
         ops.conv_gemm(y.view(B * N, nl * C)[:, :C], V["gskv"], xkv[:B * Nk], geom=(B, H1, W1, 4, 4, 4, 4, 0, 0),
                       aux0=Tkv, batch=nl, bsa=C, bsw=0, bsc=B * Nk * 2 * C)
         xkvn = _new(nl * B * Nk, 2 * C, dev)
-        ops.layernorm(xkv[:, :C], V["gsrn"][0], V["gsrn"][1], xkvn[:, :C], 1e-5)
-        ops.layernorm(xkv[:, C:], V["gsrn"][0], V["gsrn"][1], xkvn[:, C:], 1e-5)
+        # the key and the value half take the same LayerNorm (twins.py:371): rows of 2C = two rows of C in one launch
+        ops.layernorm(xkv.view(-1, C), V["gsrn"][0], V["gsrn"][1], xkvn.view(-1, C), 1e-5)
         kv = _new(nl * B * Nk, 2 * C, dev)
         ops.conv_gemm(xkvn[:, :C], V["gk"][0], kv[:, :C], aux0=Tkpe, row_mod=Nk)
         ops.conv_gemm(xkvn[:, C:], V["gv"][0], kv[:, C:], bias=V["gv"][1])
