@@ -53,6 +53,11 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=1, help="pairs per forward: 1 = BASELINE configs[1] (default), 8 = configs[2]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL; gloo for CPU rehearsal of the launcher)")
     ap.add_argument("--dry-run", action="store_true", help="launcher/collective plumbing only: no GPU, no model (tests/test_dist_cpu.py)")
+    ap.add_argument("--harness", choices=("none", "eval"), default="eval",
+                    help="eval (default, workload 512): also time the PRODUCT harness end to end -- stitch_amd.evaluate.validate_with_model over "
+                         "--harness-pairs synthetic 512x512 JPEG pairs written to a temp dir (JPEG decode + H2D + forward + metric + final "
+                         "copy inside the clock) -> harness_pairs_per_s beside value")
+    ap.add_argument("--harness-pairs", type=int, default=240)
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank computes on cuda:0 (use with --backend gloo; RCCL needs one GPU per rank)")
     return ap.parse_args(argv)
 
@@ -61,7 +66,8 @@ def parse_args(argv=None):
 def launcher_command(args, port):
     """The torchrun command line the parent starts for ``--gpus N`` (kept separate so the CPU test can check it)."""
     fwd = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
-           "--streams", str(args.streams), "--batch", str(args.batch), "--backend", args.backend]
+           "--streams", str(args.streams), "--batch", str(args.batch), "--backend", args.backend, "--harness", args.harness,
+           "--harness-pairs", str(args.harness_pairs)]
     for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-corr-roofline", args.no_corr_roofline),
                      ("--eager", args.eager), ("--dry-run", args.dry_run), ("--share-gpu", args.share_gpu)):
         if on:
@@ -198,6 +204,74 @@ def cpu_baseline_and_parity(model, ops):
     finally:
         model.load_state_dict(keep, strict=True)
     return base, parity
+
+
+def write_jpeg_split(root, n, rank_seed=0):
+    """n synthetic 512x512 pairs as UDIS-D lays them out: <root>/testing/input{1,2}/%06d.jpg (quality 95)."""
+    import numpy as np
+    from PIL import Image
+    from stitch_amd.data import structured_pair
+    for d in ("input1", "input2"):
+        os.makedirs(os.path.join(root, "testing", d), exist_ok=True)
+    base = [structured_pair(512, 512, seed=40 + i) for i in range(8)]         # 8 distinct scenes, rolled to n distinct pairs
+    for i in range(n):
+        a, b = base[i % 8]
+        for d, t in (("input1", a), ("input2", b)):
+            arr = np.roll(t[0].permute(1, 2, 0).numpy().astype(np.uint8), (3 * (i // 8), -5 * (i // 8)), (0, 1))
+            Image.fromarray(arr).save(os.path.join(root, "testing", d, f"{i:06d}.jpg"), quality=95)
+
+
+def harness_eval(model, args, rank, world, dist, log):
+    """End-to-end throughput of the product evaluation harness (evaluate.py:23-107 -> stitch_amd.evaluate.validate_with_model):
+    JPEG files on disk -> (psnr, ssim) table on the host.  Every rank takes its round-robin shard; the clock runs from before the
+    dataset is listed to after the final all-gather, max over ranks."""
+    import shutil
+    import tempfile
+    import torch
+    from stitch_amd import evaluate as sev
+    n = max(world, args.harness_pairs) * (world if world > 1 else 1)
+    root = os.path.join(tempfile.gettempdir(), f"stitch_bench_udis_{os.environ.get('MASTER_PORT', 'single')}_{n}")
+    if rank == 0:
+        shutil.rmtree(root, ignore_errors=True)
+        write_jpeg_split(root, n)
+    if dist:
+        dist.barrier()
+    try:
+        warm = sev.UDISDataset(root + "/", phase="testing")
+        warm.image_list = warm.image_list[:max(2 * args.streams, 6) * world]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        sev.validate_with_model(model, warm, streams=args.streams, device=dev)       # captures the per-slot hipGraphs, pages the files in
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        ds = sev.UDISDataset(root + "/", phase="testing")
+        result, table = sev.validate_with_model(model, ds, streams=args.streams, device=dev)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device="cuda")
+        if dist:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # the same pairs through the plain loop (eager launches, one pair at a time, .cpu() per pair): the bits must agree
+        sub = sev.UDISDataset(root + "/", phase="testing")
+        sub.image_list = sub.image_list[:4 * world]
+        t1 = time.perf_counter()
+        _, plain = sev.validate_with_model(model, sub, pipelined=False, device=dev)
+        dt_plain = time.perf_counter() - t1
+        same = bool(torch.equal(plain, table[:len(sub)]))
+        if not same:
+            log(f"plain loop vs pipelined harness differ:\n{plain}\n{table[:len(sub)]}")
+        return {"pairs": n, "seconds": tmax.item(), "pairs_per_s": n / tmax.item(), "avg_psnr": result["avg_psnr"], "avg_ssim": result["avg_ssim"],
+                "plain_loop_pairs_per_s": len(sub) / dt_plain, "plain_loop_table_equal": same,
+                "what": f"stitch_amd.evaluate.validate_with_model on {n} synthetic 512x512 JPEG pairs on disk (quality 95): PIL decode in "
+                        f"{model._eval_pipeline.workers} worker threads, pinned H2D, uint8->float + forward(test_eval) + masked PSNR/SSIM in one "
+                        f"hipGraph per pair, {args.streams} pairs in flight, one device->host copy of the table; clock = dataset listing .. "
+                        f"table on the host (graphs captured by a {len(warm)}-pair warm-up call)"}
+    finally:
+        if dist:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
 
 
 # ---------------------------------------------------------------------------------------------- one rank
@@ -339,6 +413,11 @@ def worker(args):
     if nstreams > 1:
         dt1 = timed(max(10, args.steps // 2), n_in_flight=1)       # same graphs, one pair in flight (latency-bound figure)
 
+    harness = None
+    if args.harness == "eval" and not big and not args.eager and nb == 1:
+        log("product harness (validate_with_model on JPEG pairs)")
+        harness = harness_eval(model, args, rank, world, dist, log)
+
     if rank == 0:
         log(f"timed region done: {dt:.3f} s for {args.steps} steps; instrumented step")
         inst = instrumented_step((lambda: model(a, b, type="test_out")) if big else (lambda: model(a, b, type="test_eval")))
@@ -369,6 +448,7 @@ def worker(args):
                        "pairs_in_flight": nstreams * nb,
                        "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective, one all_gather of per-pair metrics"
                                       + (" [REHEARSAL: all ranks share cuda:0]" if args.share_gpu else "")},
+            "harness_pairs_per_s": None if harness is None else harness["pairs_per_s"], "harness": harness,
             "value_1_in_flight": None if dt1 is None else world * max(10, args.steps // 2) * nb / dt1,
             "per_rank_pairs_per_s": {"min": min(per_rank_pairs_s), "max": max(per_rank_pairs_s), "ranks": len(per_rank_pairs_s)},
             "roofline": {"bound": "mfma", "kernel": "fp32 MFMA GEMM family: conv_gemm_dma_kernel + rowstream_gemm_kernel + rowchain128_kernel + conv_gemm_kernel + skinny / narrow variants + split-K reducers (every st_conv_gemm / st_linear_chain128 launch of one step)",

@@ -270,6 +270,11 @@ int st_masked_psnr_ssim(const float* image1, const float* warped, int64_t warped
 int st_channel_mean(const float* x, int64_t batch_stride, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
                     void* stream);
 
+/* Loader tail of the harnesses (core/datasets.py:383-386 `torch.from_numpy(img).permute(2,0,1).float()`, out.py:137-143):
+ * interleaved uint8 [B,H,W,3] -> planar float32 [B,3,H,W] (exact).  H*W must be a multiple of 4, src 4-byte and dst 16-byte
+ * aligned (ST_EINVAL otherwise). */
+int st_load_rgb8(const void* src_u8_hwc, float* dst_chw, int32_t B, int32_t H, int32_t W, void* stream);
+
 /* ---- operator-level entry points (one per reference operator; host-side composition of the kernels
  *      above on the caller's stream, caller-provided scratch, no allocation, no state) ------------------ */
 /* encode_flow_token with the reference's 9x9 window (decoder.py:242-260).                            */

@@ -58,23 +58,64 @@ def get_data_dict_list(data_root_path, txt_file):
     return out
 
 
-def loadSingleData(data_path, img1_name, img2_name, resize_to_512=False):
-    """out.py:129-146 (cv2.imread + BGR->RGB there; PIL RGB decode here) -> two float [1,3,H,W] tensors, 0..255."""
+def decodeSingleData(data_path, img1_name, img2_name):
+    """host half of out.py:129-136 (cv2.imread + BGR->RGB there; PIL RGB decode here): two uint8 [H,W,3] arrays.  Runs on a
+    prefetch thread one pair ahead of the GPU (PIL releases the GIL while decoding)."""
     from PIL import Image
+    return tuple(np.ascontiguousarray(np.array(Image.open(os.path.join(data_path, name)).convert("RGB")).astype(np.uint8)[..., :3])
+                 for name in (img1_name, img2_name))
+
+
+def uploadSingleData(arrays, resize_to_512=False):
+    """device half of out.py:137-143: uint8 HWC -> float [1,3,H,W] in 0..255 on the GPU (`st_load_rgb8`, exact), optional 512 resize."""
+    import stitch_amd
     ts = []
-    for name in (img1_name, img2_name):
-        arr = np.array(Image.open(os.path.join(data_path, name)).convert("RGB")).astype(np.uint8)[..., :3]
-        ts.append(torch.from_numpy(arr.copy()).permute(2, 0, 1).float().unsqueeze(0))
-    if resize_to_512:
-        import stitch_amd
-        ts = [stitch_amd.ops.resize_bilinear(t.cuda(), 512, 512, False).cpu() for t in ts]
+    for arr in arrays:
+        u8 = torch.from_numpy(arr).unsqueeze(0).cuda(non_blocking=True)
+        hw = arr.shape[0] * arr.shape[1]
+        t = stitch_amd.ops.load_rgb8(u8) if hw % 4 == 0 else u8.permute(0, 3, 1, 2).float().contiguous()
+        ts.append(stitch_amd.ops.resize_bilinear(t, 512, 512, False) if resize_to_512 else t)
     return ts[0], ts[1]
+
+
+def loadSingleData(data_path, img1_name, img2_name, resize_to_512=False):
+    """out.py:129-146 -> two float [1,3,H,W] tensors, 0..255 (host tensors, as the reference returns them)."""
+    a, b = uploadSingleData(decodeSingleData(data_path, img1_name, img2_name), resize_to_512)
+    return a.cpu(), b.cpu()
 
 
 def to_pillow(t):
     from PIL import Image
     arr = t[0].detach().cpu().permute(1, 2, 0).clip(0, 255).to(torch.uint8).numpy()
     return Image.fromarray(arr)
+
+
+class _Saver:
+    """JPEG writes of out.py:260-312.  The uint8 conversion runs on the GPU (clip + truncation, as `to_pillow_fn` does on the
+    host), the bytes are copied to the host in the caller's thread, the JPEG encode + file write go to ``pool`` when one is given
+    (``main``'s loop: the encoder releases the GIL, so the next pair's kernels are enqueued meanwhile)."""
+
+    def __init__(self, pool=None):
+        self.pool, self.futures = pool, []
+
+    def _write(self, arr, path):
+        from PIL import Image
+        Image.fromarray(arr).save(path)
+
+    def image(self, t, path):
+        arr = t[0].detach().clip(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy()
+        self.array(arr, path)
+
+    def array(self, arr, path):
+        if self.pool is None:
+            self._write(arr, path)
+        else:
+            self.futures.append(self.pool.submit(self._write, arr, path))
+
+    def wait(self):
+        for f in self.futures:
+            f.result()
+        self.futures = []
 
 
 @torch.no_grad()
@@ -91,21 +132,28 @@ def load_inpainter(name):
         return importlib.import_module("stitch_amd.mix_methods.utils.passthrough_inpainter").inpainter
 
 
-def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_model=None, inpainter=None):
+def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_model=None, inpainter=None, forward=None, saver=None):
     """out.py:158-312: forward (`test_out`), TPS post-pipeline with the configured `mix_fn`, saves, composition.  The neural
     inpainter the reference calls inside `mix_fn` is out of scope (pass-through stand-in unless the caller supplies one): in
     `warp2.jpg`, `mask2.jpg`, `ave_fusion.jpg` and the composition inputs the holes hold what `mix_fn` fills from image 1, the
-    thin border region it hands to the inpainter is not synthesised."""
-    from PIL import Image
+    thin border region it hands to the inpainter is not synthesised.
+
+    ``forward``: a callable returning the `test_out` dict of this pair whose network part is already in flight (``main``
+    launches pair i + 1's hipGraph before it finishes pair i); default = load + ``warp_model(..., type="test_out")`` here.
+    ``saver``: a ``_Saver`` (JPEG encodes on a thread pool); default = write synchronously."""
+    saver = saver or _Saver()
     path = data_dict["DATA_PATH"]
     name = os.path.basename(os.path.normpath(path))
     result_path = os.path.join(save_root_path, name) + "/"
     os.makedirs(result_path, exist_ok=True)
-    image1, image2 = loadSingleData(path if path.endswith("/") else path + "/", data_dict["IMG1"], data_dict["IMG2"],
-                                    resize_to_512=cfg.resize_to_512)
-    if getattr(cfg, "swap_image", False):
-        image1, image2 = image2, image1
-    out = warp_model(image1.cuda(), image2.cuda(), type="test_out", pad_mode=cfg.pad_mode)
+    if forward is not None:
+        out = forward()
+    else:
+        image1, image2 = uploadSingleData(decodeSingleData(path if path.endswith("/") else path + "/", data_dict["IMG1"], data_dict["IMG2"]),
+                                          resize_to_512=cfg.resize_to_512)
+        if getattr(cfg, "swap_image", False):
+            image1, image2 = image2, image1
+        out = warp_model(image1, image2, type="test_out", pad_mode=cfg.pad_mode)
     if inpainter is None:
         inpainter = load_inpainter(getattr(cfg.TPS_PIPELINE_CONFIG, "inpainter", "") or "passthrough_inpainter")
     # ---- TPS post-pipeline incl. the mix_fn plug-in (out.py:218-258, core/inference/tps_pipline.py:20-205) on the GPU
@@ -129,25 +177,71 @@ def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_m
                new_blend_image=new["new_blend_image"], tps_output=new["tps_output"], output2=new["output2"],
                mask2=new["mask2"] if new["mask2"].shape[1] == 3 else new["mask2"].expand(-1, 3, -1, -1))   # 1 channel normally; the
     #                      mix_fn branch "inpaint result all zero: not used" returns a 3-channel mask (reference: passed through as is)
-    to_pillow(out["H_warp"]).save(result_path + "H_warp.jpg")
-    to_pillow(out["final_warp"]).save(result_path + "flow_warp.jpg")
-    to_pillow(out["output1"]).save(result_path + "warp1.jpg")
-    to_pillow(out["output2"]).save(result_path + "warp2.jpg")                                             # out.py:265-272
+    saver.image(out["H_warp"], result_path + "H_warp.jpg")
+    saver.image(out["final_warp"], result_path + "flow_warp.jpg")
+    saver.image(out["output1"], result_path + "warp1.jpg")
+    saver.image(out["output2"], result_path + "warp2.jpg")                                                # out.py:265-272
     for key in ("mask1", "mask2"):
-        m = (out[key] > 0.5)[0, 0].cpu().to(torch.uint8).numpy() * 255
-        Image.fromarray(m).save(result_path + key + ".jpg")
-    to_pillow(out["new_blend_image"].float()).save(result_path + "ave_fusion.jpg")
+        saver.array((out[key] > 0.5)[0, 0].to(torch.uint8).mul(255).cpu().numpy(), result_path + key + ".jpg")
+    saver.image(out["new_blend_image"].float(), result_path + "ave_fusion.jpg")
     if composition_model is not None:
         # out.py:277-312: learned seam masks + composed image from the UDIS2 composition network
         mask1, mask2 = (out["mask1"] > 0.5).float(), (out["mask2"] > 0.5).float()
         comp = stitch_amd.composition.compose(composition_model, out["output1"], out["output2"], mask1, mask2)
-        st = ((comp["stitched_image"][0] + 1) * 127.5).cpu().numpy().transpose(1, 2, 0).clip(0, 255).astype(np.uint8)
-        Image.fromarray(st).save(result_path + "composition.jpg")
+        saver.image((comp["stitched_image"] + 1) * 127.5, result_path + "composition.jpg")
         for key in ("learned_mask1", "learned_mask2"):
-            lm = (comp[key][0] * 255).cpu().numpy().transpose(1, 2, 0).clip(0, 255).astype(np.uint8)
-            Image.fromarray(lm).save(result_path + key + ".jpg")
+            saver.image(comp[key] * 255, result_path + key + ".jpg")
         out = dict(out, **comp)
     return out, result_path
+
+
+def run_pairs(cfg, todo, save_root, model, composition_model=None, inpainter=None, on_done=None):
+    """The inference loop of out.py:351-357 as a software pipeline.  While pair i is finished on the host (canvas bounds read
+    back, canvas kernels, TPS post-pipeline with its control-point round trips, composition, device->host copies of the images),
+    pair i + 1's network part -- both nets at 512x512, ~1 000 launches, replayed from a hipGraph (`GraphedTestOut.launch`) -- is
+    already running on a second HIP stream, pair i + 2's JPEGs are being decoded, and pair i - 1's JPEGs are being encoded, both on
+    worker threads.  Two graph objects alternate so that a pair's static buffers (`residual_flow`, ...) are not overwritten before
+    its post-pipeline has consumed them.  Same kernels and the same files as calling `inference_one_data` pair by pair."""
+    from concurrent.futures import ThreadPoolExecutor
+    if not todo:
+        return []
+    graphs = [model.graphed_test_out() for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    done = []
+    with ThreadPoolExecutor(max_workers=2) as dec_pool, ThreadPoolExecutor(max_workers=4) as enc_pool:
+        def decode(dd):
+            p = dd["DATA_PATH"]
+            return decodeSingleData(p if p.endswith("/") else p + "/", dd["IMG1"], dd["IMG2"])
+
+        decoded = [dec_pool.submit(decode, dd) for dd in todo[:2]]
+
+        def launch(j):
+            k = j % 2
+            arrays = decoded[j].result()
+            if j + 2 < len(todo):
+                decoded.append(dec_pool.submit(decode, todo[j + 2]))
+            with torch.cuda.stream(streams[k]):
+                image1, image2 = uploadSingleData(arrays, resize_to_512=cfg.resize_to_512)
+                if getattr(cfg, "swap_image", False):
+                    image1, image2 = image2, image1
+                return graphs[k], graphs[k].launch(image1, image2), streams[k]
+
+        nxt = launch(0)
+        saver = _Saver(enc_pool)
+        for j, dd in enumerate(todo):
+            g, handle, st = nxt
+            nxt = launch(j + 1) if j + 1 < len(todo) else None
+            with torch.cuda.stream(st):
+                out, rp = inference_one_data(cfg, dd, save_root, model, composition_model, inpainter,
+                                             forward=lambda: g.finish(handle), saver=saver)
+            # no host wait here: the graph of this slot is launched again on the SAME stream (pair j + 2), i.e. after everything
+            # that reads this pair's static buffers
+            print("saved", rp)
+            done.append(rp)
+            if on_done is not None:
+                on_done(j, out)
+        saver.wait()
+    return done
 
 
 def shard_of_this_rank(data, rank, world):
@@ -197,12 +291,13 @@ def main(argv=None):
     os.makedirs(save_root, exist_ok=True)
     with open(save_root + "config.txt", "w") as f:
         f.write(repr(dict(cfg)))
+    todo = []
     for dd in shard_of_this_rank(get_data_dict_list(cfg.data_root_path, cfg.txt_file), rank, world):
         if cfg.skip_if_avg_fusion_exists and os.path.exists(os.path.join(save_root, os.path.basename(os.path.normpath(dd["DATA_PATH"])), "ave_fusion.jpg")):
             print("[WARNING] Skip, Due to exist", dd["DATA_PATH"])
             continue
-        _, rp = inference_one_data(cfg, dd, save_root, model, composition_model, inpainter)
-        print("saved", rp)
+        todo.append(dd)
+    run_pairs(cfg, todo, save_root, model, composition_model, inpainter)
     if world > 1:
         import torch.distributed as tdist
         tdist.barrier()

@@ -38,11 +38,13 @@ class FlowHomoAdpater(nn.Module):
         self.homo_backbone = homo_backbone
         self.flow_backbone = flow_backbone
         self._host = {}
+        self._eval_pipeline = None       # stitch_amd.evaluate.EvalPipeline: hipGraphs of the evaluation loop, captured on first use
 
     # checkpoints saved from DataParallel carry a "module." prefix (out.py:80-85)
     def load_state_dict(self, state_dict, strict=True, assign=False):
         if state_dict and all(k.startswith("module.") for k in state_dict):
             state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
+        self._eval_pipeline = None       # captured graphs point at the previous weights' packed copies
         return super().load_state_dict(state_dict, strict=strict)
 
     # ------------------------------------------------------------------ small host-side constants

@@ -414,6 +414,10 @@ __global__ __launch_bounds__(256) void range_splat_kernel(const float* __restric
             atomicAdd(acc + b * hw + (size_t)yj * W + xi, q);
         }
 }
+__global__ void zero_u64_kernel(unsigned long long* __restrict__ acc, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) acc[idx] = 0ull;
+}
 __global__ void range_finish_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ out, size_t n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < n) out[idx] = (float)((double)acc[idx] * (1.0 / 4294967296.0));
@@ -423,8 +427,9 @@ extern "C" int st_range_map(const float* flow, void* scratch_u64, float* out, in
     if (!flow || !scratch_u64 || !out || B <= 0) return ST_EINVAL;
     const size_t n = (size_t)B * H * W;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(scratch_u64, 0, n * sizeof(unsigned long long), s);
-    if (e != hipSuccess) return (int)e;
+    // zeroed by a kernel, not hipMemsetAsync: captured into a hipGraph, the memset node did not clear the accumulator on replays
+    // (ROCm 7.2: the second replay of a captured forward summed onto the first one's range map -- tools/harness_determinism6.py)
+    hipLaunchKernelGGL(zero_u64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (unsigned long long*)scratch_u64, n);
     hipLaunchKernelGGL(range_splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flow, (unsigned long long*)scratch_u64, B, H, W);
     hipLaunchKernelGGL(range_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned long long*)scratch_u64, out, n);
     ST_CHECK_LAUNCH();

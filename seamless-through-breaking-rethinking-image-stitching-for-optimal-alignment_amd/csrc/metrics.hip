@@ -104,3 +104,29 @@ extern "C" int st_channel_mean(const float* x, int64_t batch_stride, float* out,
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
+
+// Loader tail of the evaluation / inference harnesses on the GPU (core/datasets.py:383-386, out.py:137-143:
+// `torch.from_numpy(img).permute(2, 0, 1).float()`): interleaved uint8 [B,H,W,3] (what the JPEG decoder leaves in the pinned
+// staging buffer) -> planar float32 [B,3,H,W].  uint8 -> float is exact, so the planes hold the same values as the host-side
+// conversion.  A thread converts 4 consecutive pixels (three aligned dword reads, three float4 stores).
+__global__ __launch_bounds__(256) void load_rgb8_kernel(const uint32_t* __restrict__ src, float* __restrict__ dst, size_t hw, size_t quads) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;         // 4-pixel group inside image blockIdx.y
+    if (q >= quads) return;
+    const size_t b = blockIdx.y;
+    const uint32_t* s = src + (b * hw * 3) / 4 + q * 3;
+    const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];                    // r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+    float* d = dst + b * 3 * hw + q * 4;
+    *(float4*)(d) = make_float4((float)(w0 & 255u), (float)(w0 >> 24), (float)((w1 >> 16) & 255u), (float)((w2 >> 8) & 255u));
+    *(float4*)(d + hw) = make_float4((float)((w0 >> 8) & 255u), (float)(w1 & 255u), (float)(w1 >> 24), (float)((w2 >> 16) & 255u));
+    *(float4*)(d + 2 * hw) = make_float4((float)((w0 >> 16) & 255u), (float)((w1 >> 8) & 255u), (float)(w2 & 255u), (float)(w2 >> 24));
+}
+
+extern "C" int st_load_rgb8(const void* src_u8_hwc, float* dst_chw, int32_t B, int32_t H, int32_t W, void* stream) {
+    const size_t hw = (size_t)H * W;
+    if (!src_u8_hwc || !dst_chw || B <= 0 || H <= 0 || W <= 0 || (hw & 3) || ((uintptr_t)src_u8_hwc & 3) || ((uintptr_t)dst_chw & 15)) return ST_EINVAL;
+    const size_t quads = hw / 4;
+    hipLaunchKernelGGL(load_rgb8_kernel, dim3((unsigned)((quads + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src_u8_hwc, dst_chw,
+                       hw, quads);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

@@ -461,7 +461,18 @@ def tps_transform(U, source, target, out_hw, want_idx=False):
 
 
 # ---- evaluation metric --------------------------------------------------------------------------
-def masked_psnr_ssim(image1, final_warp_output):
+def load_rgb8(src_u8_hwc, out=None):
+    """core/datasets.py:383-386 / out.py:137-143 on the GPU: uint8 [B,H,W,3] (decoder layout) -> float32 [B,3,H,W]."""
+    B, H, W, c = src_u8_hwc.shape
+    if c != 3 or src_u8_hwc.dtype != torch.uint8:
+        raise ValueError(f"uint8 [B,H,W,3] expected, got {src_u8_hwc.dtype} {tuple(src_u8_hwc.shape)}")
+    if out is None:
+        out = torch.empty((B, 3, H, W), device=src_u8_hwc.device, dtype=torch.float32)
+    check(lib.st_load_rgb8(_pc(src_u8_hwc), _pc(out), B, H, W, _stream()), "st_load_rgb8")
+    return out
+
+
+def masked_psnr_ssim(image1, final_warp_output, out=None):
     """evaluate.py:44-59 on the GPU: image1 [B,3,H,W], final_warp_output [B,6,H,W] -> fp64 [B,2] (psnr, ssim)."""
     B, _, H, W = image1.shape
     dev = image1.device
@@ -470,7 +481,9 @@ def masked_psnr_ssim(image1, final_warp_output):
     check(lib.st_channel_mean(_p(mask), final_warp_output.stride(0), _p(valid), B, 3, H, W, _stream()), "st_channel_mean")
     nblk = (3 * H * W + 255) // 256
     partial = torch.empty((2 * B * nblk,), device=dev, dtype=torch.float64)
-    out = torch.empty((B, 2), device=dev, dtype=torch.float64)
+    if out is None:
+        out = torch.empty((B, 2), device=dev, dtype=torch.float64)
+    assert out.dtype == torch.float64 and out.shape == (B, 2) and out.is_contiguous()
     check(lib.st_masked_psnr_ssim(_pc(image1), _p(final_warp_output), final_warp_output.stride(0), _p(valid), _p(partial), _p(out),
                                   B, H, W, _stream()), "st_masked_psnr_ssim")
     return out
