@@ -269,3 +269,24 @@ def seeded_state_dict(seed=1234, spec=None):
     out[k + "weight"] = out[k + "weight"] * 0.12
     out[k + "bias"] = out[k + "bias"] * 0.25
     return out
+
+
+DAMPED_FLOW_SCALE = 0.15
+
+
+def damped_state_dict(seed=1234, flow_scale=DAMPED_FLOW_SCALE):
+    """``seeded_state_dict`` with the flow head's last convolution scaled by ``flow_scale`` (gru.py:5-13).
+
+    With the plain seeded weights the 12 refinement iterations amplify any rounding difference ~1.6x per iteration
+    (the coordinate update feeds the 9x9 lookup of a noise-like cost volume), so an end-to-end comparison can only be
+    read against a sensitivity control.  Scaling the per-iteration displacement by 0.15 takes the loop gain below 1
+    while the network still does real work (512x512 structured pair: |flow| up to 6.2 px, mean 1.4 px, 8 143 occluded
+    pixels): the CPU oracle moved by 1.5e-5 px in its corner offsets -- the size of the HIP / reference difference
+    there -- changes its flow by 4.5e-4 px (max) and 5 occlusion pixels, against 0.21 px and 1 586 pixels undamped.
+    On this state dict "warped-pixel L_inf < 1e-3 end to end" is a testable statement.
+    """
+    sd = seeded_state_dict(seed)
+    k = "flow_backbone.memory_decoder.update_block.flow_head.conv2."
+    sd[k + "weight"] = sd[k + "weight"] * flow_scale
+    sd[k + "bias"] = sd[k + "bias"] * flow_scale
+    return sd

@@ -198,6 +198,50 @@ def test_end_to_end_test_out_256_config1():
         assert flips <= 64, (key, flips)
 
 
+@pytest.mark.parametrize("name", ["demo1", "demo2"])
+def test_end_to_end_reference_demo_pairs_512(name, seeded_sd):
+    """The two real photo pairs the reference ships (demo/demo1, demo/demo2, 512x512 JPEGs) at native size, `test_eval` and
+    `test_out` (oracle/ref_harness/make_e2e_goldens.py).  Bit for bit in the generating container (all differences 0, no mask
+    flips); the tolerances only absorb another host's fp32 kernel choices."""
+    g = np.load(os.path.join(GOLDEN, "e2e_demo_512.npz"))
+    a = T(g[name + "_input1"]).permute(2, 0, 1)[None].float()
+    b = T(g[name + "_input2"]).permute(2, 0, 1)[None].float()
+    o = adapter.forward_test_eval(seeded_sd, a, b)
+    p = name + "_eval_"
+    close(o["H"], g[p + "H"], 1e-4, 1e-4)
+    assert np.abs(o["flow_predictions"][0][..., ::8, ::8].numpy() - g[p + "flow_sub"]).max() < 5e-3
+    assert np.abs(o["output_H"][..., ::8, ::8].numpy() - g[p + "output_H_sub"]).max() < 5e-2
+    assert np.unpackbits(_bits(o["origin_occlusion_mask"]) ^ g[p + "occ_bits"]).sum() <= 16
+    assert np.unpackbits(_bits(o["overlap"]) ^ g[p + "overlap_bits"]).sum() <= 16
+    np.testing.assert_allclose(np.array([float(o["flow_predictions"][0].double().sum()), float((o["flow_predictions"][0].double() ** 2).sum())]),
+                               g[p + "flow_cs"], rtol=1e-4)
+    o = adapter.forward_test_out(seeded_sd, a, b)
+    p = name + "_out_"
+    assert [o["width_min"], o["height_min"], o["out_height"], o["out_width"]] == list(g[p + "ints"])
+    close(o["H"], g[p + "H"], 1e-3, 1e-4)
+    close(o["I_mat"], g[p + "I_mat"], 1e-6)
+    d = np.abs(o["blend_image"][..., ::2, ::2].numpy().astype(np.int32) - g[p + "blend_sub"].astype(np.int32))
+    assert (d > 1).mean() < 1e-3, (d > 1).mean()
+    assert np.abs(o["residual_flow"][..., ::8, ::8].numpy() - g[p + "residual_flow_sub"]).max() < 5e-3
+    for key, bits in [("mask1", "mask1_bits"), ("mask2", "mask2_bits"), ("occlusion_mask", "occ_bits"),
+                      ("origin_occlusion_mask", "origin_occ_bits"), ("warp_input2_mask", "warp_mask_bits")]:
+        assert np.unpackbits(_bits(o[key]) ^ g[bits and p + bits]).sum() <= 64, key
+
+
+def test_end_to_end_damped_test_eval_512():
+    """`spec.damped_state_dict` (flow head x 0.15: loop gain of the refinement < 1): the non-chaotic end-to-end case on which
+    north_star's 'warped-pixel L_inf < 1e-3' is testable.  The golden also records the reference's own floor on this case
+    (8 vs 1 CPU threads: flow 4.5e-4 px, 5 occlusion flips)."""
+    g = np.load(os.path.join(GOLDEN, "e2e_eval_damped_512.npz"))
+    assert float(g["flow_scale"]) == spec.DAMPED_FLOW_SCALE and float(g["flow_absmax"]) > 5.0 and int(g["occluded_px"]) > 5000
+    assert float(g["ref_floor_flow_max_px"]) < 1e-3 and int(g["ref_floor_occ_flips"]) <= 5
+    a, b = inputs.structured_pair(512, 512, seed=7)
+    o = adapter.forward_test_eval(spec.damped_state_dict(1234), a, b)
+    close(o["H"], g["H"], 1e-4, 1e-4)
+    assert np.abs(o["flow_predictions"][0][..., ::4, ::4].numpy() - g["flow_sub"]).max() < 1e-3
+    assert np.unpackbits(_bits(o["origin_occlusion_mask"]) ^ g["occ_bits"]).sum() <= 3 * max(1, int(g["ref_floor_occ_flips"]))
+
+
 def test_composition_oracle_matches_reference_golden():
     """oracle/composition.py against the reference's own Network / build_model output
     (tests/golden/composition_512x544.npz, written by oracle/ref_harness/make_composition_golden.py)."""
