@@ -102,20 +102,24 @@ def instrumented_step(run_step):
     import stitch_amd
     lib, GemmDesc = stitch_amd._lib.lib, stitch_amd._lib.GemmDesc
     rec, open_ev = [], []
+    plan = (C.c_int32 * 4)()
 
     @C.CFUNCTYPE(None, C.POINTER(GemmDesc), C.c_void_p, C.c_int32, C.c_void_p)
     def observer(desc, stream, phase, user):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream())
         if phase == 0:
+            open_ev.append(ev)
+        else:
             d = desc.contents
+            lib.st_gemm_last_plan(plan)
             nb = max(1, d.batch)
             a_rows = d.M if d.kh * d.kw <= 1 else (d.M // max(1, d.Ho * d.Wo)) * d.H * d.W       # conv: input pixels
-            abytes = 4.0 * nb * (a_rows * d.Cin + d.N * d.K + d.M * d.N)                         # A + W + C, fp32
-            open_ev.append((2.0 * d.M * d.N * d.K * nb, abytes, ev))
-        else:
-            flops, abytes, e0 = open_ev.pop()
-            rec.append((flops, abytes, e0, ev))
+            if plan[0] in (5, 6):       # fused row kernels, reported as M x 128 L x 128 / M x 2 hidden x 128: rows in, weights, rows out
+                abytes = 4.0 * (2 * d.M * 128 + d.N * d.K) + (4.0 * d.M * 128 if plan[0] == 6 else 0.0)      # (+ the MLP's residual re-read)
+            else:
+                abytes = 4.0 * nb * (a_rows * d.Cin + d.N * d.K + d.M * d.N * (2 if d.c_t else 1))          # A + W + C (+ transposed copy), fp32
+            rec.append((2.0 * d.M * d.N * d.K * nb, abytes, open_ev.pop(), ev))
 
     lib.st_set_gemm_observer(C.cast(observer, C.c_void_p), None)
     st = torch.cuda.current_stream()
@@ -140,6 +144,15 @@ def instrumented_step(run_step):
     raw = [r[2].elapsed_time(r[3]) for r in rec]
     return dict(flops=sum(r[0] for r in rec), ms_raw=sum(raw), ms=sum(max(0.0, t - ov) for t in raw), launches=len(rec),
                 alg_bytes=sum(r[1] for r in rec), bracket_overhead_us=1e3 * ov)
+
+
+def provenance(path):
+    """file name + mtime + content hash of a committed profile summary quoted in the line: a stale file cannot be quoted silently."""
+    import hashlib
+    import datetime
+    raw = open(path, "rb").read()
+    return {"file": os.path.relpath(path, ROOT), "mtime_utc": datetime.datetime.utcfromtimestamp(os.path.getmtime(path)).strftime("%Y-%m-%dT%H:%M:%SZ"),
+            "sha16": hashlib.sha256(raw).hexdigest()[:16], "head": raw[:96].decode("utf-8", "replace").replace("\n", " ")}
 
 
 def corr_roofline(ops, B=8, N=4096, C=256, iters=10):
@@ -424,18 +437,22 @@ def worker(args):
         flops, gemm_ms, launches, abytes = inst["flops"], inst["ms"], inst["launches"], inst["alg_bytes"]
         tf = flops / gemm_ms / 1e9
         traffic, tsrc = None, None             # HBM bytes per step of the GEMM family from the committed PMC passes
-        for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and not big and nb == 1:
                 t = json.load(open(tpath))
                 traffic = t["fetch_bytes_per_step"] + t["write_bytes_per_step"]
-                tsrc = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied)"
+                tsrc = dict(provenance(tpath), how="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied "
+                                                   "(tools/run_pmc_shapes.sh)", launches_per_step_in_file=t.get("launches_per_step"))
                 break
-        # per-kernel time of the same command from the committed rocprofv3 pass (tools/prof_bench.sh -> profiles/r3_kernel_summary.json)
-        prof = None
-        ppath = os.path.join(ROOT, "profiles", "r3_kernel_summary.json")
-        if os.path.exists(ppath) and not big and nb == 1:
-            prof = json.load(open(ppath))
+        # per-kernel time of the same command from the committed rocprofv3 pass (tools/final_prof.sh -> profiles/r4_kernel_summary.json)
+        prof, psrc = None, None
+        for name in ("r4_kernel_summary.json", "r3_kernel_summary.json"):
+            ppath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(ppath) and not big and nb == 1:
+                prof = json.load(open(ppath))
+                psrc = dict(provenance(ppath), how=prof.get("source"))
+                break
         wl = ("synthetic 1024x1024 pairs, 4 per GPU, batch=1, FlowHomoAdpater.forward(type=test_out)" if big else
               f"UDIS-D-shaped 512x512 pairs, batch={nb}, FlowHomoAdpater.forward(type=test_eval)")
         out = {
@@ -451,7 +468,7 @@ def worker(args):
             "harness_pairs_per_s": None if harness is None else harness["pairs_per_s"], "harness": harness,
             "value_1_in_flight": None if dt1 is None else world * max(10, args.steps // 2) * nb / dt1,
             "per_rank_pairs_per_s": {"min": min(per_rank_pairs_s), "max": max(per_rank_pairs_s), "ranks": len(per_rank_pairs_s)},
-            "roofline": {"bound": "mfma", "kernel": "fp32 MFMA GEMM family: conv_gemm_dma_kernel + rowstream_gemm_kernel + rowchain128_kernel + conv_gemm_kernel + skinny / narrow variants + split-K reducers (every st_conv_gemm / st_linear_chain128 launch of one step)",
+            "roofline": {"bound": "mfma", "kernel": "fp32 MFMA GEMM family: conv_gemm_dma_kernel + rowstream_gemm_kernel + rowmlp128_kernel + rowchain128_kernel + conv_gemm_kernel + skinny / narrow variants + split-K reducers (every st_conv_gemm / st_mlp128 / st_linear_chain128 launch of one step)",
                          "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)", "traffic_source": tsrc,
                          "algorithmic_bytes": abytes, "launches_per_step": launches, "gflop_per_step": flops / 1e9,
@@ -466,7 +483,9 @@ def worker(args):
                          "kernel_ms_per_step_rocprof": None if prof is None else prof.get("gemm_family_ms_per_forward"),
                          "frac_rocprof": None if prof is None else flops / 1e9 / prof["gemm_family_ms_per_forward"] / FP32_MFMA_PEAK_TFLOPS,
                          "other_kernels_ms_per_step": None if prof is None else prof.get("other_kernels_ms_per_forward"),
-                         "rocprof_source": None if prof is None else prof.get("source")},
+                         "rocprof_source": psrc,
+                         "stale_profile_warning": None if (tsrc is None or tsrc.get("launches_per_step_in_file") in (None, launches)) else
+                         f"the committed PMC pass saw {tsrc['launches_per_step_in_file']} launches per step, this run {launches}: `traffic` is from an older build"},
             "corr_volume": None if args.no_corr_roofline else corr_roofline(ops),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -94,7 +94,8 @@ int st_set_gemm_observer(void* callback, void* user);
 
 /* Profiling aid: the launch plan the library chose for the calling thread's most recent st_conv_gemm:
  *   plan4[0] kernel family (0 skinny_gemm, 1 narrow_conv, 2 conv_gemm_kernel [register-staged], 3 conv_gemm_dma_kernel,
- *            4 rowstream_gemm_kernel, 5 rowchain128_kernel [st_linear_chain128, reported to the observer as M x 128L x 128])
+ *            4 rowstream_gemm_kernel, 5 rowchain128_kernel [st_linear_chain128, reported to the observer as M x 128L x 128],
+ *            6 rowmlp128_kernel [st_mlp128, reported as M x 2 hidden x 128])
  *   plan4[1] tile_cfg actually used, plan4[2] split_k actually used, plan4[3] 1 = persistent M walk, 2 / 3 = first / second
  *            member of an st_conv_gemm_pair launch (one dispatch, reported with the second member).
  * Used by tools/gemm_shapes_csv.py to label every launch of a step (profiles/r2_gemm_shapes.csv). */
@@ -109,8 +110,9 @@ int st_abi_gemm_desc_size(void);
  *   x_0 = a;   x_{l+1} = act_l( LN_l(x_l) . w_l^T + bias_l ) + residual_l ;   out = x_nlayers
  * LN_l (ln = 1): layer norm of the row WITHOUT affine (the caller folds gamma / beta into w_l / bias_l);
  * residual_l: res = 0 none, 1 = rows of the global matrix res_ptr (row stride ld_res), 2 = x_{res_layer} (an earlier
- * layer's input before its LN).  w_l [128,128] row-major contiguous, bias_l [128].  Same k pairing and summation order per
- * layer as st_conv_gemm (bit-identical to the unfused chain).                                                          */
+ * layer's input before its LN).  w_l [128,128] row-major contiguous, bias_l [128], both 16-byte aligned.  Same k pairing and
+ * summation order per layer as st_conv_gemm (bit-identical to the unfused chain).  The kernel keeps ONE saved layer input:
+ * all res = 2 layers of a chain must name the same res_layer (ST_EINVAL otherwise).                                      */
 typedef struct st_chain_layer {
     const float* w;
     const float* bias;
@@ -131,6 +133,28 @@ typedef struct st_chain_desc {
 int st_linear_chain128(const st_chain_desc* desc, void* stream);
 int st_abi_chain_desc_size(void);
 
+/* The Twins / vertical-layer MLP of C = 128 rows (timm Mlp inside Block, twins.py:785-790; encoder.py:121-125):
+ *   out = a + ( GELU( LN(a) . w1^T + b1 ) . w2^T + b2 ) [+ res]
+ * as one launch (rowmlp128_kernel): the [M, hidden] activations never reach HBM.  LN (ln = 1): layer norm WITHOUT affine, the
+ * caller folds gamma / beta into w1 / b1.  w1 [hidden, 128], w2 [128, hidden] row-major contiguous; b1 [hidden], b2 [128];
+ * hidden % 32 == 0, 32..2048; every pointer 16-byte aligned; out must not alias a.  fc1 + GELU are bit-identical to
+ * st_conv_gemm(act = gelu); fc2 sums its `hidden` products in one chain (st_conv_gemm folds every 256 k): same products, the
+ * last bits of the sum differ.  plan4[0] = 6; reported to the observer as M x 2 hidden x 128.                                 */
+typedef struct st_mlp_desc {
+    const float* a;        /* [M, lda], 128 columns used: input and first residual                                         */
+    float* out;            /* [M, ldo]                                                                                    */
+    const float* w1;
+    const float* b1;
+    const float* w2;
+    const float* b2;
+    const float* res;      /* optional second residual [M, ld_res] (encoder.py:281 short-cut), or NULL                    */
+    int32_t lda, ldo, ld_res, M, hidden, ln;
+    float ln_eps;
+    int32_t reserved;      /* must be 0                                                                                   */
+} st_mlp_desc;
+int st_mlp128(const st_mlp_desc* desc, void* stream);
+int st_abi_mlp_desc_size(void);
+
 /* All-pairs correlation volume, MemoryEncoder.corr (encoder.py:359-369):
  *   f1, f2 [B, N, C] channels-last features -> vol [B, N1, N2] = f1 . f2^T (no scaling). */
 int st_corr_volume(const float* f1, const float* f2, float* vol, int32_t B, int32_t N1, int32_t N2,
@@ -140,6 +164,10 @@ int st_corr_volume(const float* f1, const float* f2, float* vol, int32_t B, int3
  * other shapes run as two products).                                                                                  */
 int st_corr_volume_both(const float* f1, const float* f2, float* vol12, float* vol21, int32_t B, int32_t N, int32_t C,
                         void* stream);
+/* The dispatch decision of st_corr_volume_both, without launching (host only): returns 1 = one product + transposed second store,
+ * 0 = two st_corr_volume products (shape / alignment of the LDS-DMA kernel not met, or N * N * 4 >= 2^31: the transposed copy
+ * and the row-chunked path exclude each other).  aligned16: all of f1, f2, vol21 are 16-byte aligned.                     */
+int st_corr_volume_both_plan(int32_t B, int32_t N, int32_t C, int32_t aligned16);
 
 /* ---- row-wise network ops (channels-last rows) ------------------------------------------------ */
 /* nn.LayerNorm over the last dim (encoder.py:58,140-141; twins.py:752-790, eps 1e-5 / 1e-6).        */

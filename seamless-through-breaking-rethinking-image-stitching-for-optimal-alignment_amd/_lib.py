@@ -52,6 +52,12 @@ class ChainDesc(C.Structure):
                 ("layer", ChainLayer * 3)]
 
 
+class MlpDesc(C.Structure):
+    """Mirror of ``st_mlp_desc``."""
+    _fields_ = ([(n, C.c_void_p) for n in ("a", "out", "w1", "b1", "w2", "b2", "res")]
+                + [(n, C.c_int32) for n in ("lda", "ldo", "ld_res", "M", "hidden", "ln")] + [("ln_eps", C.c_float), ("reserved", C.c_int32)])
+
+
 def declared_functions(header=HEADER):
     """{name: [ctypes argtypes]} for every ``int st_*(...)`` declaration in the header."""
     src = open(header).read()

@@ -14,6 +14,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = {"gemm.hip": [], "nn.hip": [], "flowops.hip": [], "geom.hip": ["-ffp-contract=off"],
            "metrics.hip": ["-ffp-contract=off"], "operators.hip": [], "composition.hip": ["-ffp-contract=off"], "tps_pipeline.hip": ["-ffp-contract=off"]}
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+if os.environ.get("ST_EXACT_TRANSCENDENTALS", "0") == "1":       # diagnostic build (csrc/common.h): not the shipped arithmetic
+    COMMON.append("-DST_EXACT_TRANSCENDENTALS")
 
 
 def _stale(target, deps):

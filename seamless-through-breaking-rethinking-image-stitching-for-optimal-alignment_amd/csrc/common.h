@@ -29,6 +29,14 @@ enum {
 // Phi(x) = 1 - erfc(s) / 2 for x >= 0 and erfc(s) / 2 for x < 0 -- the negative side has no 1 + erf cancellation.
 // Measured against the fp64 value on 4 M points of [-10, 10]: max abs error 4.7e-7, max relative error 1.7e-5 where
 // |gelu| > 1e-2; torch's own fp32 CPU GELU (the reference's arithmetic): 1.2e-6 and 6.4e-5.
+// ST_EXACT_TRANSCENDENTALS (diagnostic build only: `ST_EXACT_TRANSCENDENTALS=1 python <pkg>/build.py --force`): ocml's erff / expf / tanhf with IEEE
+// division instead of the three fast forms below -- used once per round to attribute parity drift to the epilogue arithmetic
+// (profiles/r4_exact_transcendentals.txt); never shipped: ~2x the VALU instructions on the datapath the fp32 MFMA shares.
+#ifdef ST_EXACT_TRANSCENDENTALS
+__device__ __forceinline__ float st_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float st_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float st_tanh(float v) { return tanhf(v); }
+#else
 __device__ __forceinline__ float st_gelu(float x) {
     const float s = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, s, 1.0f));
@@ -52,6 +60,7 @@ __device__ __forceinline__ float st_tanh(float v) {
     const float e = __builtin_amdgcn_exp2f(fabsf(v) * -2.88539008177792681472f);
     return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), v);
 }
+#endif
 
 __device__ __forceinline__ float st_act(float v, int act) {
     switch (act) {

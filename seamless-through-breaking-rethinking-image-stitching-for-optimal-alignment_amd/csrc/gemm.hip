@@ -999,7 +999,8 @@ __global__ __launch_bounds__(512) void rowstream_gemm_kernel(const st_gemm_desc 
 // operand, activations second): a chunk's accumulators are then row li's output features 8 jj + 4 lh + t, i.e. four more float4 of
 // the NEXT layer's A operand -- bias, activation, LayerNorm and the residual adds happen in that layout, in registers, and nothing
 // crosses LDS between layers.  Weights stream through a 3-stage LDS ring of 32-row chunks shared by the waves of the workgroup
-// (LDS DMA, XOR-swizzled 128-B-row image as in conv_gemm_dma_kernel; one barrier per chunk, the chunk two steps ahead in flight).
+// (LDS DMA, XOR-swizzled 128-B-row image as in conv_gemm_dma_kernel; one barrier per chunk; the DMA of chunk q + 2 is issued at the
+// start of step q, but every step opens with s_waitcnt vmcnt(0), so a chunk has ONE step -- 64 MFMAs per wave -- to land, not two).
 // Per layer the k pairing and summation order are those of the other kernels: bit-identical.
 #define RC_NW 4                                                  // waves per workgroup, two workgroups per CU (starting half of them half a
                                                                  // step late so that co-resident waves run out of phase: measured neutral)
@@ -1080,8 +1081,9 @@ __global__ __launch_bounds__(256, 2) void rowchain128_kernel(const st_chain_desc
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c, ++q) {
-                // chunk q (DMA issued two steps ago, waited for at the end of the previous step) is in the ring once every wave's
-                // pieces have landed; everyone is past chunk q - 1, whose stage chunk q + 2 may now overwrite
+                // chunk q (DMA issued two steps ago; the vmcnt(0) below also drains chunk q + 1, issued one step ago, so the ring's
+                // effective lead is one step) is in the ring once every wave's pieces have landed; everyone is past chunk q - 1,
+                // whose stage chunk q + 2 may now overwrite
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (q + 2 < total) dma_chunk(q + 2);
@@ -1166,6 +1168,17 @@ extern "C" int st_linear_chain128(const st_chain_desc* desc, void* stream) {
         if (!y.w || ((uintptr_t)y.w & 15) || y.act < 0 || y.act > ST_ACT_GELU || y.res < 0 || y.res > 2) return ST_EINVAL;
         if (y.res == 1 && (!y.res_ptr || y.ld_res < 128 || (y.ld_res & 3) || ((uintptr_t)y.res_ptr & 15))) return ST_EINVAL;
         if (y.res == 2 && (y.res_layer < 0 || y.res_layer > l)) return ST_EINVAL;
+        if (y.bias && ((uintptr_t)y.bias & 15)) return ST_EINVAL;        // read with 16-byte loads
+    }
+    {
+        // the kernel keeps ONE saved layer input (`sv`): every res == 2 layer must name the same res_layer -- a second one would
+        // overwrite the copy a later layer still needs and silently add the wrong tensor
+        int saved = -1;
+        for (int l = 0; l < d.nlayers; ++l)
+            if (d.layer[l].res == 2) {
+                if (saved >= 0 && d.layer[l].res_layer != saved) return ST_EINVAL;
+                saved = d.layer[l].res_layer;
+            }
     }
     const int nblk = (d.M + 31) / 32;
     int G = (nblk + RC_NW - 1) / RC_NW;
@@ -1185,6 +1198,212 @@ extern "C" int st_linear_chain128(const st_chain_desc* desc, void* stream) {
     }
     g_last_plan[0] = 5; g_last_plan[1] = 30; g_last_plan[2] = 1; g_last_plan[3] = 1;
     hipLaunchKernelGGL(rowchain128_kernel, dim3(G), dim3(64 * RC_NW), lds, (hipStream_t)stream, d);
+    if (obs) obs(&od, stream, 1, g_observer_user);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The Twins MLP (timm Mlp, twins.py:785-790: x + fc2(GELU(fc1(LN(x)))), C = 128, hidden = 512) as ONE launch: the hidden
+// activations never leave the CU.  Unfused, fc1's [M, 512] tensor is written and read back: 268 MB per MLP at M = 65536, and fc1
+// and fc2 are two K = 128 / N = 128 launches at 0.53 / 0.66 of the fp32-MFMA peak (profiles/r3_gemm_shapes.csv).
+// Structure = rowchain128_kernel's: a wave owns a 32-row block whose LayerNorm'ed rows sit in registers in the MFMA operand
+// layout; the hidden dimension is walked in chunks of 32 features:
+//   stage A   h = GELU(W1[32 hc .. +32, :] . x^T + b1)     64 MFMAs, TRANSPOSED product (weights first): lane (li, lh) then holds
+//             row li's hidden features 8 j + 4 lh + t of the chunk -- the operand layout of the k slice [32 hc, 32 hc + 32) of fc2
+//   stage B   o[oc] += W2[32 oc .. +32, 32 hc .. +32] . h^T, oc = 0..3     64 MFMAs, transposed again: four accumulator tiles whose
+//             layout is the block's own row layout, so bias, the residual x (re-read: it is L2-warm) and the optional second
+//             residual are added in registers and stored as 16-byte runs.
+// Per step the workgroup's four waves share W1's chunk (32 x 128) and W2's slice (128 x 32) through a 2-stage LDS ring filled by
+// LDS-DMA one step ahead (32 KB per stage, 64 KB per workgroup, two workgroups per CU), one barrier per step.  k pairing and order
+// inside both products are those of the other kernels (k = 8 j + 4 lane_half + t); fc1 is bit-identical to the unfused launch,
+// fc2 accumulates its 512 k in ONE chain (the unfused kernels fold at k = 256; holding that fold would need 64 more registers
+// per lane than two waves per SIMD have) -- same products, the sum differs in the last bits.
+#define MLP_NW 4
+__global__ __launch_bounds__(256, 2) void rowmlp128_kernel(const st_mlp_desc d) {
+    constexpr int NJ = 16, NW = MLP_NW, STAGE = 2 * 32 * 128;   // floats per ring stage: [W1 chunk 32 x 128 | W2 slice 128 x 32]
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int nblk = (d.M + 31) >> 5;
+    const int G = (int)gridDim.x;
+    const int blk0 = (int)blockIdx.x * NW;
+    const int rounds = blk0 < nblk ? (nblk - blk0 + G * NW - 1) / (G * NW) : 0;
+    const int nhc = d.hidden >> 5, total = rounds * nhc;
+    if (total == 0) return;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const i32x4 rs1 = make_rsrc(d.w1, (unsigned)d.hidden * 128u * 4u), rs2 = make_rsrc(d.w2, 128u * (unsigned)d.hidden * 4u);
+
+    // step q = hidden chunk hc = q % nhc -> ring stage q & 1.  W1 chunk: 16 pieces of 1 KiB = two 512-B rows, slot s of row r holds
+    // k-chunk s ^ (r & 15) (rowchain128's image).  W2 slice: 16 pieces of 1 KiB = eight 128-B rows, slot s of row r holds k-chunk
+    // s ^ ((r >> 1) & 7) (conv_gemm_dma's image).  The swizzles are applied on the source side; 8 pieces per wave and step.
+    auto dma_step = [&](int q) {
+        const int hc = q % nhc;
+        const unsigned st = lds0 + (unsigned)((q & 1) * STAGE * 4);
+#pragma unroll
+        for (int u = 0; u < 16 / NW; ++u) {
+            const int p = wave * (16 / NW) + u, r = 2 * p + (lane >> 5);
+            const unsigned voff = (unsigned)((((hc << 5) + r) * 128 + (((lane & 31) ^ (r & 15)) << 2)) * 4);
+            lds_dma16(rs1, st + (unsigned)(p * 1024), voff, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 16 / NW; ++u) {
+            const int p = wave * (16 / NW) + u, r = 8 * p + (lane >> 3);
+            const unsigned voff = (unsigned)((r * d.hidden + (((lane & 7) ^ ((r >> 1) & 7)) << 2)) * 4);
+            lds_dma16(rs2, st + (unsigned)(32 * 128 * 4 + p * 1024), voff, (unsigned)(hc << 7));
+        }
+    };
+    dma_step(0);
+    if (total > 1) dma_step(1);                                 // both stages are free at the start
+    int foff[8], goff[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) foff[j] = (((2 * j + lh) ^ (li & 15)) << 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) goff[j] = li * 32 + (((2 * j + lh) ^ ((li >> 1) & 7)) << 2);
+
+    float4 a[NJ];
+    int q = 0;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int blk = blk0 + wave + rd * G * NW;
+        const bool active = blk < nblk;                         // wave-uniform; idle waves still load weights and meet the barriers
+        const int row = blk * 32 + li;
+        const bool rok = active && row < d.M;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                a[j] = rok ? *reinterpret_cast<const float4*>(d.a + (size_t)row * d.lda + 8 * j + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.ln) {                                         // LayerNorm without affine (gamma / beta are folded into w1 / b1): as rowchain128
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) s += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+                s += __shfl_xor(s, 32, 64);
+                const float mean = s * (1.0f / 128.0f);
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    a[j].x -= mean; a[j].y -= mean; a[j].z -= mean; a[j].w -= mean;
+                    v += (a[j].x * a[j].x + a[j].y * a[j].y) + (a[j].z * a[j].z + a[j].w * a[j].w);
+                }
+                v += __shfl_xor(v, 32, 64);
+                const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + d.ln_eps);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { a[j].x *= rstd; a[j].y *= rstd; a[j].z *= rstd; a[j].w *= rstd; }
+            }
+        }
+        f32x16 o[4];
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[oc][r] = 0.f;
+        for (int hc = 0; hc < nhc; ++hc, ++q) {
+            // step q's weights (DMA issued one step ago) are in the ring once every wave's pieces have landed; everyone is past
+            // step q - 1, whose stage step q + 1 may now overwrite
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (q > 0 && q + 1 < total) dma_step(q + 1);
+            if (active) {
+                const float* w1s = smem + (q & 1) * STAGE + li * 128;
+                const float* w2s = smem + (q & 1) * STAGE + 32 * 128;
+                float4 bv[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bv[jj] = *reinterpret_cast<const float4*>(d.b1 + (hc << 5) + 8 * jj + 4 * lh);
+                // ---- stage A: hidden chunk, K = 128
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                float4 b = *reinterpret_cast<const float4*>(w1s + foff[0]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int jn = j + 1 < NJ ? j + 1 : j;
+                    const float4 bn = *reinterpret_cast<const float4*>(w1s + foff[jn & 7] + (jn >> 3) * 64);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[j].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[j].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[j].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[j].w, acc, 0, 0, 0);
+                    b = bn;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // first W2 fragments of stage B are requested before the GELU arithmetic
+                float4 g[4];
+#pragma unroll
+                for (int oc = 0; oc < 4; ++oc) g[oc] = *reinterpret_cast<const float4*>(w2s + oc * 1024 + goff[0]);
+                float4 hq[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    hq[jj].x = st_gelu(acc[4 * jj] + bv[jj].x); hq[jj].y = st_gelu(acc[4 * jj + 1] + bv[jj].y);
+                    hq[jj].z = st_gelu(acc[4 * jj + 2] + bv[jj].z); hq[jj].w = st_gelu(acc[4 * jj + 3] + bv[jj].w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- stage B: the chunk is the k slice [32 hc, 32 hc + 32) of fc2; four independent accumulator tiles
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 gn[4];
+                    const int jn = j + 1 < 4 ? j + 1 : j;
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) gn[oc] = *reinterpret_cast<const float4*>(w2s + oc * 1024 + goff[jn]);
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) o[oc] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[oc].x, hq[j].x, o[oc], 0, 0, 0);
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) o[oc] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[oc].y, hq[j].y, o[oc], 0, 0, 0);
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) o[oc] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[oc].z, hq[j].z, o[oc], 0, 0, 0);
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) o[oc] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[oc].w, hq[j].w, o[oc], 0, 0, 0);
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) g[oc] = gn[oc];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (rok) {
+            // out = (fc2 + b2) + x [+ res]: the unfused epilogue's order (fma(acc, 1, bias), + aux0, + aux1)
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int col = oc * 32 + 8 * jj + 4 * lh;
+                    const float4 bb = *reinterpret_cast<const float4*>(d.b2 + col);
+                    const float4 x = *reinterpret_cast<const float4*>(d.a + (size_t)row * d.lda + col);
+                    float4 v = make_float4((o[oc][4 * jj] + bb.x) + x.x, (o[oc][4 * jj + 1] + bb.y) + x.y, (o[oc][4 * jj + 2] + bb.z) + x.z,
+                                           (o[oc][4 * jj + 3] + bb.w) + x.w);
+                    if (d.res) {
+                        const float4 e = *reinterpret_cast<const float4*>(d.res + (size_t)row * d.ld_res + col);
+                        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+                    }
+                    *reinterpret_cast<float4*>(d.out + (size_t)row * d.ldo + col) = v;
+                }
+        }
+    }
+}
+
+extern "C" int st_abi_mlp_desc_size(void) { return (int)sizeof(st_mlp_desc); }
+
+extern "C" int st_mlp128(const st_mlp_desc* desc, void* stream) {
+    if (!desc) return ST_EINVAL;
+    const st_mlp_desc& d = *desc;
+    if (!d.a || !d.out || !d.w1 || !d.b1 || !d.w2 || !d.b2 || d.M <= 0 || d.hidden < 32 || d.hidden > 2048 || (d.hidden & 31) || d.lda < 128 ||
+        d.ldo < 128 || (d.lda & 3) || (d.ldo & 3) || d.reserved != 0 || (int64_t)d.M * (d.lda > d.ldo ? d.lda : d.ldo) >= ((int64_t)1 << 40))
+        return ST_EINVAL;
+    if ((((uintptr_t)d.a | (uintptr_t)d.out | (uintptr_t)d.w1 | (uintptr_t)d.b1 | (uintptr_t)d.w2 | (uintptr_t)d.b2) & 15)) return ST_EINVAL;
+    if (d.res && (d.ld_res < 128 || (d.ld_res & 3) || ((uintptr_t)d.res & 15))) return ST_EINVAL;
+    if (d.a == d.out) return ST_EINVAL;                        // the residual x is re-read at the end of a block: not in place
+    const int nblk = (d.M + 31) / 32;
+    int G = (nblk + MLP_NW - 1) / MLP_NW;
+    if (G > 512) G = 512;                                       // two workgroups per CU
+    const size_t lds = (size_t)(2 * 2 * 32 * 128) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)rowmlp128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the profiling observer sees the MLP as one launch of the family: M x (2 * hidden) x 128 = its FLOPs (2 M 128 hidden per product)
+    st_gemm_observer_fn obs = g_observer;
+    st_gemm_desc od;
+    if (obs) {
+        memset(&od, 0, sizeof(od));
+        od.a = d.a; od.c = d.out; od.w = d.w1;
+        od.M = d.M; od.N = 2 * d.hidden; od.K = 128; od.H = 1; od.W = d.M; od.Cin = 128; od.ldx = d.lda; od.ldc = d.ldo; od.ldw = 128;
+        od.kh = od.kw = od.sh = od.sw = 1; od.Ho = 1; od.Wo = d.M; od.batch = 1; od.alpha = 1.f;
+        obs(&od, stream, 0, g_observer_user);
+    }
+    g_last_plan[0] = 6; g_last_plan[1] = 31; g_last_plan[2] = 1; g_last_plan[3] = 1;
+    hipLaunchKernelGGL(rowmlp128_kernel, dim3(G), dim3(64 * MLP_NW), lds, (hipStream_t)stream, d);
     if (obs) obs(&od, stream, 1, g_observer_user);
     ST_CHECK_LAUNCH();
     return ST_OK;
@@ -1678,11 +1897,23 @@ extern "C" int st_corr_volume(const float* f1, const float* f2, float* vol, int3
     return st_conv_gemm(&d, stream);
 }
 
+// 1 = one product with a transposed second store, 0 = two products.  The transposed store needs a shape of the LDS-DMA kernel
+// (N % 4 == 0, C % 32 == 0, C >= 128, 16-byte aligned operands) AND a volume that the 32-bit buffer offsets reach in one piece:
+// N * N * 4 < 2^31 for the transposed copy (conv_gemm_launch rejects c_t otherwise) and (N + 256) * N * 4 < 2^31, f1 / f2 extents
+// < 2^31 for the row-chunked path, which cannot carry c_t (N > ~23 000, i.e. flow grids beyond ~1 200 x 1 200 pixels / 8).
+extern "C" int st_corr_volume_both_plan(int32_t B, int32_t N, int32_t C, int32_t aligned16) {
+    if (B <= 0 || N <= 0 || C <= 0) return 0;
+    if ((N & 3) || C % 32 || C < 128 || !aligned16) return 0;
+    const int64_t lim = (int64_t)1 << 31;
+    if ((int64_t)N * N * 4 >= lim || ((int64_t)N + 256) * N * 4 >= lim || ((int64_t)(N - 1) * C + C) * 4 >= (int64_t)ST_OOB) return 0;
+    return 1;
+}
+
 extern "C" int st_corr_volume_both(const float* f1, const float* f2, float* vol12, float* vol21, int32_t B, int32_t N, int32_t C,
                                    void* stream) {
     if (!f1 || !f2 || !vol12 || !vol21 || B <= 0 || N <= 0 || C <= 0) return ST_EINVAL;
-    if ((N & 3) || C % 32 || C < 128 || (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)vol21) & 15)) {
-        // not a shape of the LDS-DMA kernel (which carries the transposed store): two products
+    if (!st_corr_volume_both_plan(B, N, C, (int32_t)((((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)vol21) & 15) == 0))) {
+        // not a shape of the LDS-DMA kernel's transposed store: two products
         const int rc = st_corr_volume(f1, f2, vol12, B, N, N, C, stream);
         return rc ? rc : st_corr_volume(f2, f1, vol21, B, N, N, C, stream);
     }

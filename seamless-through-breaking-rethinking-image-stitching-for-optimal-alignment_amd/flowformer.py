@@ -31,6 +31,7 @@ from .homography import pack_conv
 # folded into the weights at pack time.  ST_FUSE_LN=0 keeps the separate LayerNorm kernel (A/B measurements).
 FUSE_LN = os.environ.get("ST_FUSE_LN", "1") != "0"
 PAIR_CONVS = os.environ.get("ST_PAIR_CONVS", "1") != "0"       # convc2 + convf2 of the motion encoder as one launch
+FUSE_MLP = os.environ.get("ST_FUSE_MLP", "1") != "0"            # the C = 128 Twins MLPs (LN -> fc1 + GELU -> fc2 + residual) as one st_mlp128 launch
 FUSE_CHAIN = os.environ.get("ST_FUSE_CHAIN", "1") != "0"        # the latent layers' 128-wide tails as one st_linear_chain128 launch
 
 
@@ -212,6 +213,9 @@ class FlowFormer(ParamTree):
     @staticmethod
     def _mlp(x, n2, fc1, fc2, eps, out=None, fc1_ln=None, extra_res=None):
         dev = x.device
+        if fc1_ln is not None and FUSE_LN and FUSE_MLP and x.shape[1] == 128 and fc2[0].is_contiguous() and fc1_ln[0].is_contiguous():
+            o = _new(x.shape[0], 128, dev) if out is None else out
+            return ops.mlp128(x, o, fc1_ln[0], fc1_ln[1], fc2[0], fc2[1], ln_eps=eps, res=extra_res)
         h = _new(x.shape[0], fc1[0].shape[0], dev)
         if fc1_ln is not None and FUSE_LN:
             ops.conv_gemm(x, fc1_ln[0], h, bias=fc1_ln[1], act="gelu", ln_eps=eps)

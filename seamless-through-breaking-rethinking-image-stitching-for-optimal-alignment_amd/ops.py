@@ -6,7 +6,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import ChainDesc, GemmDesc, check, lib
+from ._lib import ChainDesc, GemmDesc, MlpDesc, check, lib
 from ._lib import StitchError as StitchErrorBase
 
 ACT = dict(none=0, relu=1, gelu=2, sigmoid=3, tanh=4)
@@ -14,6 +14,7 @@ EPI = dict(store=0, add=1, mul=2, gru=3, axpy=4, zr=5)
 
 assert lib.st_abi_gemm_desc_size() == C.sizeof(GemmDesc), "st_gemm_desc ABI mismatch between header and binding"
 assert lib.st_abi_chain_desc_size() == C.sizeof(ChainDesc), "st_chain_desc ABI mismatch between header and binding"
+assert lib.st_abi_mlp_desc_size() == C.sizeof(MlpDesc), "st_mlp_desc ABI mismatch between header and binding"
 
 
 def _stream():
@@ -178,6 +179,23 @@ def linear_chain128(a, out, layers):
         else:
             ly.res, ly.res_ptr, ly.ld_res = 1, r.data_ptr(), _ld(r)
     check(lib.st_linear_chain128(C.byref(d), _stream()), "st_linear_chain128")
+    return out
+
+
+def mlp128(a, out, w1, b1, w2, b2, ln_eps=None, res=None):
+    """out = a + (GELU(LN(a) @ w1^T + b1) @ w2^T + b2) [+ res] over the 128-wide rows of ``a`` in one launch (st_mlp128: the hidden
+    activations stay on the CU).  ln_eps None = no LayerNorm (otherwise without affine: fold gamma / beta into w1 / b1)."""
+    hidden = w1.shape[0]
+    assert w1.shape == (hidden, 128) and w2.shape == (128, hidden) and w1.is_contiguous() and w2.is_contiguous()
+    assert b1.shape == (hidden,) and b2.shape == (128,) and a.shape[1] == 128 and out.shape == a.shape
+    d = MlpDesc()
+    d.a, d.out, d.lda, d.ldo, d.M, d.hidden = a.data_ptr(), out.data_ptr(), _ld(a), _ld(out), a.shape[0], hidden
+    d.w1, d.b1, d.w2, d.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    d.ln, d.ln_eps = (1, float(ln_eps)) if ln_eps is not None else (0, 0.0)
+    if res is not None:
+        assert res.shape == a.shape
+        d.res, d.ld_res = res.data_ptr(), _ld(res)
+    check(lib.st_mlp128(C.byref(d), _stream()), "st_mlp128")
     return out
 
 

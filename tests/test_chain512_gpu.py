@@ -141,7 +141,7 @@ def test_chain_512_end_to_end(chain):
     assert same_pts, "control point sites differ"               # integer sites from the Sobel sampling of H_warp
     check("chain512_e2e_points_dst_max_px", dpts, 0.05)          # measured 1.6e-2
     #          # site + box-averaged flow: inherits the end-to-end flow gap
-    check("chain512_e2e_mask2_flip_frac", mflip, 3e-3)                                  # measured 1.1e-3
-    check("chain512_e2e_blend_gt2_frac", (db > 2).float().mean(), 1e-2)                  # measured 3.9e-3
-    check("chain512_e2e_stitched_p99", np.percentile(ds.numpy(), 99), 2e-2)              # measured 6.6e-3
+    check("chain512_e2e_mask2_flip_frac", mflip, 9e-4)                                  # measured 2.8e-4 (r3 build: 1.1e-3 -- a chaotic e2e figure: it moves with every change of summation order)
+    check("chain512_e2e_blend_gt2_frac", (db > 2).float().mean(), 3.4e-3)                # measured 1.1e-3 (r3 build: 3.9e-3)
+    check("chain512_e2e_stitched_p99", np.percentile(ds.numpy(), 99), 1e-2)              # measured 3.3e-3 (r3 build: 6.6e-3)
     assert torch.isfinite(comp["stitched_image"]).all()

@@ -293,7 +293,7 @@ def test_end_to_end_damped_eval_512_vs_reference_golden(damped_model):
     H = o["H"].cpu().numpy()
     check("damped_e2e_H_rel", np.abs(H - g["H"]).max() / max(1.0, np.abs(g["H"]).max()), 3.6e-6)      # measured 1.2e-6
     dflow = np.abs(o["flow_predictions"][0][..., ::4, ::4].cpu().numpy() - g["flow_sub"])
-    check("damped_e2e_flow_max_px", dflow.max(), 1e-3)                                   # north_star's bound; measured 2.5e-4 (reference vs itself: 4.5e-4)
+    check("damped_e2e_flow_max_px", dflow.max(), 7.5e-4)                                   # north_star's bound; measured 2.5e-4 (reference vs itself: 4.5e-4)
     check("damped_e2e_flow_p99_px", np.percentile(dflow, 99), 3.6e-4)      # measured 1.2e-4
     occ_flip = np.unpackbits(_bits(o["origin_occlusion_mask"]) ^ g["occ_bits"]).sum()
     check("damped_e2e_occ_flips", occ_flip, 3 * int(g["ref_floor_occ_flips"]), inclusive=True)      # <= 3x the reference's own floor (15); measured 4
@@ -322,22 +322,22 @@ def test_end_to_end_reference_demo_pairs_512(model, name):
     o = model(a, b, type="test_eval")
     p = name + "_eval_"
     H = o["H"].cpu().numpy()
-    check(f"{name}_eval_H_rel", np.abs(H - g[p + "H"]).max() / max(1.0, np.abs(g[p + "H"]).max()), 4e-6)
+    check(f"{name}_eval_H_rel", np.abs(H - g[p + "H"]).max() / max(1.0, np.abs(g[p + "H"]).max()), 3.3e-6)      # measured 1.0e-6 / 1.1e-6
     dflow = np.abs(o["flow_predictions"][0][..., ::8, ::8].cpu().numpy() - g[p + "flow_sub"])
-    check(f"{name}_eval_flow_max_px", dflow.max(), 0.2)      # measured 0.076 / 0.019 (demo1 / demo2)
-    check(f"{name}_eval_flow_p99_px", np.percentile(dflow, 99), 0.05)      # measured 0.018 / 0.0057
-    check(f"{name}_eval_output_H_p99", np.percentile(np.abs(o["output_H"][..., ::8, ::8].cpu().numpy() - g[p + "output_H_sub"]), 99), 1.2e-2)      # measured 4.1e-3 / 2.8e-3
-    check(f"{name}_eval_occ_flips", np.unpackbits(_bits(o["origin_occlusion_mask"]) ^ g[p + "occ_bits"]).sum(), 2400)      # measured 795 / 450
-    check(f"{name}_eval_overlap_flips", np.unpackbits(_bits(o["overlap"]) ^ g[p + "overlap_bits"]).sum(), 15)      # measured 5 / 1
+    check(f"{name}_eval_flow_max_px", dflow.max(), {"demo1": 0.23, "demo2": 0.055}[name])      # measured 0.076 / 0.018 (demo1 / demo2)
+    check(f"{name}_eval_flow_p99_px", np.percentile(dflow, 99), {"demo1": 0.054, "demo2": 0.017}[name])      # measured 0.018 / 0.0055
+    check(f"{name}_eval_output_H_p99", np.percentile(np.abs(o["output_H"][..., ::8, ::8].cpu().numpy() - g[p + "output_H_sub"]), 99), {"demo1": 1.2e-2, "demo2": 8.4e-3}[name])      # measured 4.1e-3 / 2.8e-3
+    check(f"{name}_eval_occ_flips", np.unpackbits(_bits(o["origin_occlusion_mask"]) ^ g[p + "occ_bits"]).sum(), {"demo1": 2400, "demo2": 1370}[name])      # measured 785 / 457
+    check(f"{name}_eval_overlap_flips", np.unpackbits(_bits(o["overlap"]) ^ g[p + "overlap_bits"]).sum(), {"demo1": 15, "demo2": 3}[name], inclusive=True)      # measured 5 / 1
     o = model(a, b, type="test_out")
     p = name + "_out_"
     assert [o["width_min"], o["height_min"], o["out_height"], o["out_width"]] == list(g[p + "ints"])      # canvas ints exact
-    check(f"{name}_out_H_rel", np.abs(o["H"].cpu().numpy() - g[p + "H"]).max() / max(1.0, np.abs(g[p + "H"]).max()), 2.4e-6)      # measured 8e-7 / 5e-7
+    check(f"{name}_out_H_rel", np.abs(o["H"].cpu().numpy() - g[p + "H"]).max() / max(1.0, np.abs(g[p + "H"]).max()), {"demo1": 2.4e-6, "demo2": 1.6e-6}[name])      # measured 8e-7 / 5.3e-7
     assert np.abs(o["I_mat"].cpu().numpy() - g[p + "I_mat"]).max() < 1e-6
     d = np.abs(o["blend_image"][..., ::2, ::2].cpu().numpy().astype(np.int32) - g[p + "blend_sub"].astype(np.int32))
-    check(f"{name}_out_blend_gt2_frac", (d > 2).mean(), 2.6e-3)      # measured 8.8e-4 / 3.4e-4
+    check(f"{name}_out_blend_gt2_frac", (d > 2).mean(), {"demo1": 2.6e-3, "demo2": 1e-3}[name])      # measured 8.8e-4 / 3.4e-4
     drf = np.abs(o["residual_flow"][..., ::8, ::8].cpu().numpy() - g[p + "residual_flow_sub"])
-    check(f"{name}_out_residual_flow_p99_px", np.percentile(drf, 99), 0.05)      # measured 0.018 / 0.0057
+    check(f"{name}_out_residual_flow_p99_px", np.percentile(drf, 99), {"demo1": 0.054, "demo2": 0.017}[name])      # measured 0.018 / 0.0055
     for key, bits in [("mask1", "mask1_bits"), ("warp_input2_mask", "warp_mask_bits")]:
         check(f"{name}_out_{key}_flip_frac", np.unpackbits(_bits(o[key]) ^ g[p + bits]).sum() / o[key].numel(), 1e-4)
     for key, bits in [("mask2", "mask2_bits"), ("occlusion_mask", "occ_bits"), ("origin_occlusion_mask", "origin_occ_bits")]:
@@ -355,16 +355,19 @@ def test_forward_batch8_matches_single_pairs(model):
     o8 = model(A, Bt, type="test_eval")
     assert o8["final_warp_output"].shape == (8, 6, 512, 512) and o8["H"].shape == (8, 3, 3)
     assert torch.isfinite(o8["final_warp_output"]).all()
+    worst = dict(H=0.0, flow_max_px=0.0, flow_p99_px=0.0, occ_flips=0.0)          # one bound per quantity = 3x its maximum over the samples
     for i in (0, 3, 7):
         o1 = model(A[i:i + 1], Bt[i:i + 1], type="test_eval")
         dH = (o8["H"][i] - o1["H"][0]).abs().max().item()
         d = (o8["flow_predictions"][0][i] - o1["flow_predictions"][0][0]).abs()
         flips = int((o8["origin_occlusion_mask"][i] != o1["origin_occlusion_mask"][0]).sum())
         print(f"[batch 8 vs 1, sample {i}] H {dH:.2e} flow max {d.max().item():.3e} p99 {np.percentile(d.cpu().numpy(), 99):.3e} occ flips {flips}")
-        check(f"batch8_vs_1_H_{i}", dH, 3e-6)                                  # measured <= 9.5e-7
-        check(f"batch8_vs_1_flow_max_px_{i}", d.max(), 0.4)                    # measured <= 0.124
-        check(f"batch8_vs_1_flow_p99_px_{i}", np.percentile(d.cpu().numpy(), 99), 0.06)      # measured <= 0.019
-        check(f"batch8_vs_1_occ_flips_{i}", flips, 2600)                       # measured <= 976
+        for k, v in (("H", dH), ("flow_max_px", d.max().item()), ("flow_p99_px", np.percentile(d.cpu().numpy(), 99)), ("occ_flips", flips)):
+            worst[k] = max(worst[k], float(v))
+    check("batch8_vs_1_H", worst["H"], 3e-6)                       # measured 9.5e-7 (sample 3)
+    check("batch8_vs_1_flow_max_px", worst["flow_max_px"], 0.34)   # measured 0.114 (sample 3)
+    check("batch8_vs_1_flow_p99_px", worst["flow_p99_px"], 0.06)   # measured 0.0195
+    check("batch8_vs_1_occ_flips", worst["occ_flips"], 2800)       # measured 952
 
 
 def test_graph_replay_and_concurrent_streams_match_eager(model):

@@ -792,6 +792,52 @@ def test_linear_chain128(ops, M):
     assert torch.equal(o2, ou)
 
 
+@pytest.mark.parametrize("M,hidden", [(2048, 512), (4099, 512), (96, 256), (17, 32)])
+def test_mlp128_fused(ops, M, hidden):
+    """st_mlp128: x + fc2(GELU(fc1(LN(x)))) [+ second residual] of the C = 128 Twins / vertical-layer MLPs (twins.py:785-790) in ONE
+    launch, the hidden activations staying on the CU: against fp64 torch, against the unfused launches (fc1 + GELU bit-identical by
+    construction; fc2 sums its k in one chain where st_conv_gemm folds every 256: last-bit differences only), ragged M, column
+    slices of wider buffers, no-LayerNorm form, and the rejected descriptors."""
+    gg = g(11)
+    x, extra = torch.randn(M, 128, generator=gg) * 1.5, torch.randn(M, 128, generator=gg)
+    w1, b1 = torch.randn(hidden, 128, generator=gg) / 128 ** 0.5, torch.randn(hidden, generator=gg) * 0.1
+    w2, b2 = torch.randn(128, hidden, generator=gg) / hidden ** 0.5, torch.randn(128, generator=gg) * 0.1
+    gam, bet = torch.rand(128, generator=gg) + 0.5, torch.randn(128, generator=gg) * 0.1
+    xd = x.double()
+    h = F.gelu(F.linear(F.layer_norm(xd, (128,), gam.double(), bet.double(), 1e-6), w1.double(), b1.double()))
+    ref = F.linear(h, w2.double(), b2.double()) + xd
+    w1f, b1f = ops.fold_layernorm(dev(gam), dev(bet), dev(w1), dev(b1))
+    xw = torch.zeros(M, 136, device="cuda")
+    xw[:, 4:132] = x.cuda()
+    out = torch.full((M, 136), 7.0, device="cuda")
+    ops.mlp128(xw[:, 4:132], out[:, 4:132], w1f, b1f, dev(w2), dev(b2), ln_eps=1e-6)
+    scale = ref.abs().max().item()
+    check(f"mlp128_vs_fp64_rel_{M}_{hidden}", (out[:, 4:132].cpu().double() - ref).abs().max() / scale, 1.6e-6)      # measured 3.5e-7 .. 5.1e-7
+    assert (out[:, :4] == 7.0).all() and (out[:, 132:] == 7.0).all()
+    # the unfused launches
+    hu, ou = torch.empty(M, hidden, device="cuda"), torch.empty(M, 128, device="cuda")
+    ops.conv_gemm(dev(x), w1f, hu, bias=b1f, act="gelu", ln_eps=1e-6)
+    ops.conv_gemm(hu, dev(w2), ou, bias=dev(b2), aux0=dev(x))
+    if hidden <= 256:
+        assert torch.equal(out[:, 4:132], ou)              # no fold below 256 k: the same chain, the same bits
+    else:
+        check(f"mlp128_vs_unfused_rel_{M}_{hidden}", (out[:, 4:132] - ou).abs().max().item() / scale, 1e-6)
+    # second residual (the cost-memory short-cut in the last vertical layer, encoder.py:281) + the no-LayerNorm form
+    o2, o2u = torch.empty(M, 128, device="cuda"), torch.empty(M, 128, device="cuda")
+    ops.mlp128(dev(x), o2, dev(w1), dev(b1), dev(w2), dev(b2), res=dev(extra))
+    ops.conv_gemm(dev(x), dev(w1), hu, bias=dev(b1), act="gelu")
+    ops.conv_gemm(hu, dev(w2), o2u, bias=dev(b2), aux0=dev(x), epi="add", aux1=dev(extra))
+    ref2 = F.linear(F.gelu(F.linear(xd, w1.double(), b1.double())), w2.double(), b2.double()) + xd + extra.double()
+    assert (o2.cpu().double() - ref2).abs().max() / ref2.abs().max() < 6e-6
+    assert (o2 - o2u).abs().max().item() / scale < 1e-6
+    if M == 96:
+        with pytest.raises(ops.StitchErrorBase):
+            xc = dev(x)
+            ops.mlp128(xc, xc, dev(w1), dev(b1), dev(w2), dev(b2))                            # in place: rejected
+        with pytest.raises(ops.StitchErrorBase):
+            ops.mlp128(dev(x), o2, dev(w1), torch.zeros(hidden + 4, device="cuda")[1:hidden + 1], dev(w2), dev(b2))     # bias not 16-byte aligned
+
+
 @pytest.mark.parametrize("kh,kw,ph,pw", [(1, 5, 0, 2), (3, 3, 1, 1)])
 def test_gemm_second_a_source(ops, kh, kw, ph, pw):
     """st_gemm_desc.a2: input channels < a2_channels come from a second buffer of the same geometry (SepConvGRU's q conv reads

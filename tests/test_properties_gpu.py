@@ -86,13 +86,17 @@ def test_batch_independence(model):
     o = model(A, Bm, type="test_eval")
     assert o["final_warp_output"].shape == (2, 6, 512, 512) and o["origin_occlusion_mask"].shape == (2, 512, 512)
     fwd, bwd = model.predict_flow_pair(A, Bm)
+    worst = dict(H=0.0, output_H=0.0, flow_fwd_px=0.0, flow_bwd_px=0.0)            # one bound per quantity = 3x its maximum over the samples
     for i, (a, b) in enumerate(((a0, b0), (a1, b1))):
         s = model(a.cuda(), b.cuda(), type="test_eval")
-        check(f"batch2_vs_1_H_{i}", (o["H"][i] - s["H"][0]).abs().max(), 4e-6)                     # measured 1.2e-6
-        check(f"batch2_vs_1_output_H_{i}", (o["output_H"][i] - s["output_H"][0]).abs().max(), 4.5e-2)   # measured 1.4e-2 grey levels
         f1, b1_ = model.predict_flow_pair(a.cuda(), b.cuda())
-        check(f"batch2_vs_1_flow_fwd_px_{i}", (fwd[i] - f1[0]).abs().max(), 6e-2)      # measured 1.8e-2
-        check(f"batch2_vs_1_flow_bwd_px_{i}", (bwd[i] - b1_[0]).abs().max(), 6e-2)   # |flow| ~ 30 px; fp32 reorder (other split-K at 2x rows) x 12 iterations
+        for k, v in (("H", (o["H"][i] - s["H"][0]).abs().max()), ("output_H", (o["output_H"][i] - s["output_H"][0]).abs().max()),
+                     ("flow_fwd_px", (fwd[i] - f1[0]).abs().max()), ("flow_bwd_px", (bwd[i] - b1_[0]).abs().max())):
+            worst[k] = max(worst[k], float(v))
+    check("batch2_vs_1_H", worst["H"], 3.6e-6)                     # measured 1.2e-6
+    check("batch2_vs_1_output_H", worst["output_H"], 4.2e-2)       # measured 1.4e-2 grey levels
+    check("batch2_vs_1_flow_fwd_px", worst["flow_fwd_px"], 4.5e-2)   # measured 1.5e-2
+    check("batch2_vs_1_flow_bwd_px", worst["flow_bwd_px"], 4.5e-2)   # measured 1.5e-2; |flow| ~ 30 px; fp32 reorder (other split-K at 2x rows) x 12 iterations
 
 
 def test_test_out_1024_vs_oracle(model, seeded_sd):
@@ -243,7 +247,7 @@ def test_batch_of_four_pairs_runs_and_matches_single(model):
     fwd, bwd = model.predict_flow_pair(A, Bm)
     assert fwd.shape == (4, 2, 512, 512) and torch.isfinite(fwd).all() and torch.isfinite(bwd).all()
     f1, b1 = model.predict_flow_pair(pairs[2][0].cuda(), pairs[2][1].cuda())
-    check("batch4_vs_1_flow_fwd_px", (fwd[2] - f1[0]).abs().max(), 5e-2)      # measured 1.1e-2 / 1.5e-2
-    check("batch4_vs_1_flow_bwd_px", (bwd[2] - b1[0]).abs().max(), 5e-2)
+    check("batch4_vs_1_flow_fwd_px", (fwd[2] - f1[0]).abs().max(), 4.4e-2)      # measured 1.5e-2
+    check("batch4_vs_1_flow_bwd_px", (bwd[2] - b1[0]).abs().max(), 4.2e-2)      # measured 1.4e-2
     o = model(A, Bm, type="test_eval")
     assert o["final_warp_output"].shape == (4, 6, 512, 512) and torch.isfinite(o["final_warp_output"]).all()

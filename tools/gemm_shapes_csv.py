@@ -21,7 +21,8 @@ import sys
 
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 
-FAMILY = {0: "skinny_gemm_kernel", 1: "narrow_conv_kernel", 2: "conv_gemm_kernel", 3: "conv_gemm_dma_kernel", 4: "rowstream_gemm_kernel", 5: "rowchain128_kernel"}
+FAMILY = {0: "skinny_gemm_kernel", 1: "narrow_conv_kernel", 2: "conv_gemm_kernel", 3: "conv_gemm_dma_kernel", 4: "rowstream_gemm_kernel", 5: "rowchain128_kernel",
+          6: "rowmlp128_kernel"}
 PEAK = 157.3
 
 
@@ -58,9 +59,18 @@ def timing_pass(out_csv, launches_json=None, profile_only=False):
         nb = max(1, d.batch)
         conv = d.kh * d.kw > 1 or d.sh > 1
         a_rows = (d.M // max(1, d.Ho * d.Wo)) * d.H * d.W if conv else d.M
+        w_bytes = 4.0 * nb * d.N * d.K
+        if plan[0] in (5, 6):
+            # fused row kernels (reported as M x 128 L x 128 / M x 2 hidden x 128): the intermediate activations never move --
+            # A rows in, weights, 128-wide rows out (+ the residual rows re-read by the MLP kernel)
+            alg = 4.0 * (d.M * 128 + d.M * 128) + w_bytes + (4.0 * d.M * 128 if plan[0] == 6 else 0.0)
+        else:
+            alg = 4.0 * nb * (a_rows * d.Cin + d.M * d.N) + w_bytes
+            if d.c_t:
+                alg += 4.0 * nb * d.M * d.N                       # the transposed second store of st_corr_volume_both
         rec.append(dict(M=d.M, N=d.N, K=d.K, conv=f"{d.kh}x{d.kw}s{d.sh}" + (f"d{d.dh}" if d.dh > 1 else ""), batch=nb,
                         kernel=FAMILY.get(plan[0], "?"), tile=plan[1], split_k=plan[2], persist=plan[3], epi=d.epi,
-                        flops=2.0 * d.M * d.N * d.K * nb, alg_bytes=4.0 * nb * (a_rows * d.Cin + d.N * d.K + d.M * d.N),
+                        flops=2.0 * d.M * d.N * d.K * nb, alg_bytes=alg, w_bytes=w_bytes,
                         ev=(open_ev.pop(), ev)))
 
     lib.st_set_gemm_observer(C.cast(observer, C.c_void_p), None)
@@ -101,7 +111,7 @@ def merge_pairs(rec):
             m = dict(r)
             o = rec[i + 1]
             m.update(N=f"{r['N']}+{o['N']}", kernel="conv_gemm_dma_pair_kernel", persist=0, us=r["us"] + o["us"], flops=r["flops"] + o["flops"],
-                     alg_bytes=r["alg_bytes"] + o["alg_bytes"])
+                     alg_bytes=r["alg_bytes"] + o["alg_bytes"], w_bytes=r.get("w_bytes", 0.0) + o.get("w_bytes", 0.0))
             if "fetch_bytes" in o:
                 m["fetch_bytes"] = r.get("fetch_bytes", 0.0) + o["fetch_bytes"]
                 m["write_bytes"] = r.get("write_bytes", 0.0) + o["write_bytes"]
@@ -116,7 +126,8 @@ def merge_pairs(rec):
 def write_csv(out_csv, rec):
     agg = collections.OrderedDict()
     for r in merge_pairs(rec):
-        g = agg.setdefault(shape_key(r), dict(launches=0, us=0.0, flops=0.0, alg=0.0, fetch=0.0, write=0.0, pmc=0))
+        g = agg.setdefault(shape_key(r), dict(launches=0, us=0.0, flops=0.0, alg=0.0, fetch=0.0, write=0.0, pmc=0, w=0.0))
+        g["w"] += r.get("w_bytes", 0.0)
         g["launches"] += 1
         g["us"] += r["us"]
         g["flops"] += r["flops"]
@@ -131,7 +142,7 @@ def write_csv(out_csv, rec):
         w.writerow(["M", "N", "K", "conv", "batch", "kernel", "tile_cfg", "split_k", "persistent", "epilogue", "launches_per_step",
                     "us_per_launch", "ms_per_step", "share_of_gemm_time", "TFLOP/s", "frac_of_fp32_mfma_peak", "GFLOP_per_launch",
                     "algorithmic_MB_per_launch", "pmc_fetch_MB_per_launch", "pmc_write_MB_per_launch", "pmc_over_algorithmic",
-                    "HBM_GB/s_algorithmic"])
+                    "HBM_GB/s_algorithmic", "weights_x7_MB_per_launch", "pmc_over_algorithmic_8xcd"])
         for key, g in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):
             n = g["launches"]
             tf = g["flops"] / g["us"] / 1e6 if g["us"] else 0.0
@@ -139,11 +150,15 @@ def write_csv(out_csv, rec):
             w.writerow(list(key[:10]) + [n, f"{g['us'] / n:.1f}", f"{g['us'] / 1e3:.3f}", f"{g['us'] / tot_us:.4f}" if tot_us else "",
                                         f"{tf:.1f}", f"{tf / PEAK:.3f}", f"{g['flops'] / n / 1e9:.3f}", f"{g['alg'] / n / 1e6:.2f}",
                                         "" if pmc is None else f"{g['fetch'] / n / 1e6:.2f}", "" if pmc is None else f"{g['write'] / n / 1e6:.2f}",
-                                        "" if pmc is None else f"{pmc / g['alg']:.2f}", f"{g['alg'] / g['us'] / 1e3:.0f}" if g["us"] else ""])
+                                        "" if pmc is None else f"{pmc / g['alg']:.2f}", f"{g['alg'] / g['us'] / 1e3:.0f}" if g["us"] else "",
+                                        # the 8 XCDs have private L2s: every XCD that runs tiles of a launch fetches its own copy of the weight panel, so
+                                        # the floor of the L2-miss traffic (what FETCH_SIZE counts) is A + C + 8 W, not A + C + W
+                                        f"{7 * g['w'] / n / 1e6:.2f}", "" if pmc is None else f"{pmc / (g['alg'] + 7 * g['w']):.2f}"])
         tf = sum(g["flops"] for g in agg.values()) / tot_us / 1e6 if tot_us else 0.0
         w.writerow(["TOTAL", "", "", "", "", "", "", "", "", "", sum(g["launches"] for g in agg.values()), "", f"{tot_us / 1e3:.3f}", "1.0",
                     f"{tf:.1f}", f"{tf / PEAK:.3f}", "", f"{sum(g['alg'] for g in agg.values()) / 1e6:.1f}",
-                    f"{sum(g['fetch'] for g in agg.values()) / 1e6:.1f}", f"{sum(g['write'] for g in agg.values()) / 1e6:.1f}", "", ""])
+                    f"{sum(g['fetch'] for g in agg.values()) / 1e6:.1f}", f"{sum(g['write'] for g in agg.values()) / 1e6:.1f}", "", "",
+                    f"{7 * sum(g['w'] for g in agg.values()) / 1e6:.1f}", ""])
     print(open(out_csv).read())
 
 
@@ -154,7 +169,7 @@ def join(out_csv, launches_json, fetch_csv, write_csv_path):
         rows = []
         for r in csv.DictReader(open(path)):
             k = re.sub(r"\(.*", "", r["Kernel_Name"]).strip()
-            if any(s in k for s in ("conv_gemm", "skinny_gemm", "narrow_conv", "splitk_reduce", "rowstream_gemm", "rowchain128")):
+            if any(s in k for s in ("conv_gemm", "skinny_gemm", "narrow_conv", "splitk_reduce", "rowstream_gemm", "rowchain128", "rowmlp128")):
                 rows.append((int(r.get("Dispatch_Id", len(rows))), k, float(r["Counter_Value"])))
         rows.sort()
         return rows
@@ -175,7 +190,11 @@ def join(out_csv, launches_json, fetch_csv, write_csv_path):
     write_csv(out_csv, rec)
     tot = dict(fetch_bytes_per_step=sum(r["fetch_bytes"] for r in rec), write_bytes_per_step=sum(r["write_bytes"] for r in rec),
                algorithmic_bytes_per_step=sum(r["alg_bytes"] for r in rec), launches_per_step=len(rec),
-               kernel="conv_gemm_dma_kernel + conv_gemm_kernel + skinny/narrow variants + split-K reducers (all st_conv_gemm launches of one step)",
+               weight_bytes_per_step=sum(r.get("w_bytes", 0.0) for r in rec),
+               algorithmic_bytes_per_step_8xcd=sum(r["alg_bytes"] + 7 * r.get("w_bytes", 0.0) for r in rec),
+               note_8xcd="FETCH_SIZE counts L2 misses; the 8 XCDs have private L2s, so a weight panel is fetched once per XCD: the floor of this "
+                         "counter is A + C + 8 W (algorithmic_bytes_per_step_8xcd), most of the 7 extra copies being served by the Infinity Cache",
+               kernel="conv_gemm_dma_kernel + conv_gemm_kernel + rowstream / rowchain128 / rowmlp128 + skinny/narrow variants + split-K reducers (all launches of the family in one step)",
                corrections="FETCH_SIZE KiB x2 (MI355X_MICROARCH.md HBM section), WRITE_SIZE KiB x1",
                source="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/gemm_shapes_csv.py x.csv --profile-only")
     json.dump(tot, open(out_csv.replace("gemm_shapes.csv", "traffic.json"), "w"), indent=1)
