@@ -195,46 +195,51 @@ def inference_one_data(cfg, data_dict, save_root_path, warp_model, composition_m
     return out, result_path
 
 
-def run_pairs(cfg, todo, save_root, model, composition_model=None, inpainter=None, on_done=None):
-    """The inference loop of out.py:351-357 as a software pipeline.  While pair i is finished on the host (canvas bounds read
-    back, canvas kernels, TPS post-pipeline with its control-point round trips, composition, device->host copies of the images),
-    pair i + 1's network part -- both nets at 512x512, ~1 000 launches, replayed from a hipGraph (`GraphedTestOut.launch`) -- is
-    already running on a second HIP stream, pair i + 2's JPEGs are being decoded, and pair i - 1's JPEGs are being encoded, both on
-    worker threads.  Two graph objects alternate so that a pair's static buffers (`residual_flow`, ...) are not overwritten before
-    its post-pipeline has consumed them.  Same kernels and the same files as calling `inference_one_data` pair by pair."""
+def run_pairs(cfg, todo, save_root, model, composition_model=None, inpainter=None, on_done=None, depth=2):
+    """The inference loop of out.py:351-357 as a software pipeline, `depth` pairs in flight.  While pair i is finished on the host
+    (canvas bounds read back, canvas kernels, TPS post-pipeline with its control-point round trips, composition, device->host copies
+    of the images), the network parts of pairs i + 1 .. i + depth - 1 -- both nets at 512x512, ~1 000 launches each, replayed from a
+    hipGraph (`GraphedTestOut.launch`) -- are already running on their own HIP streams, the JPEGs of the pairs after them are being
+    decoded, and pair i - 1's JPEGs are being encoded, both on worker threads.  `depth` graph objects alternate so that a pair's static
+    buffers (`residual_flow`, ...) are not overwritten before its post-pipeline has consumed them.  Same kernels and the same files
+    as calling `inference_one_data` pair by pair (tests/test_harness_gpu.py).  Measured on 48 synthetic 512x512 pairs, 10 JPEGs written per
+    pair (tools/bench_out_harness.py, profiles/r4_out_harness.json): 36.9 pairs/s pair by pair, 60.0 at depth 2 (default), 51 at depth 3 / 4
+    (a third network graph in flight only delays the canvas / TPS / composition kernels of the pair the host is waiting for)."""
     from concurrent.futures import ThreadPoolExecutor
     if not todo:
         return []
-    graphs = [model.graphed_test_out() for _ in range(2)]
-    streams = [torch.cuda.Stream() for _ in range(2)]
+    depth = max(1, int(depth))
+    graphs = [model.graphed_test_out() for _ in range(depth)]
+    streams = [torch.cuda.Stream() for _ in range(depth)]
     done = []
     with ThreadPoolExecutor(max_workers=2) as dec_pool, ThreadPoolExecutor(max_workers=4) as enc_pool:
         def decode(dd):
             p = dd["DATA_PATH"]
             return decodeSingleData(p if p.endswith("/") else p + "/", dd["IMG1"], dd["IMG2"])
 
-        decoded = [dec_pool.submit(decode, dd) for dd in todo[:2]]
+        decoded = [dec_pool.submit(decode, dd) for dd in todo[:depth + 1]]
 
         def launch(j):
-            k = j % 2
+            k = j % depth
             arrays = decoded[j].result()
-            if j + 2 < len(todo):
-                decoded.append(dec_pool.submit(decode, todo[j + 2]))
+            if j + depth + 1 < len(todo):
+                decoded.append(dec_pool.submit(decode, todo[j + depth + 1]))
             with torch.cuda.stream(streams[k]):
                 image1, image2 = uploadSingleData(arrays, resize_to_512=cfg.resize_to_512)
                 if getattr(cfg, "swap_image", False):
                     image1, image2 = image2, image1
                 return graphs[k], graphs[k].launch(image1, image2), streams[k]
 
-        nxt = launch(0)
+        inflight = [launch(j) for j in range(min(depth - 1, len(todo)))]
         saver = _Saver(enc_pool)
         for j, dd in enumerate(todo):
-            g, handle, st = nxt
-            nxt = launch(j + 1) if j + 1 < len(todo) else None
+            if j + depth - 1 < len(todo):
+                inflight.append(launch(j + depth - 1))
+            g, handle, st = inflight.pop(0)
             with torch.cuda.stream(st):
                 out, rp = inference_one_data(cfg, dd, save_root, model, composition_model, inpainter,
                                              forward=lambda: g.finish(handle), saver=saver)
-            # no host wait here: the graph of this slot is launched again on the SAME stream (pair j + 2), i.e. after everything
+            # no host wait here: the graph of this slot is launched again on the SAME stream (pair j + depth), i.e. after everything
             # that reads this pair's static buffers
             print("saved", rp)
             done.append(rp)
