@@ -219,15 +219,16 @@ def cpu_baseline_and_parity(model, ops):
     return base, parity
 
 
-def write_jpeg_split(root, n, rank_seed=0):
-    """n synthetic 512x512 pairs as UDIS-D lays them out: <root>/testing/input{1,2}/%06d.jpg (quality 95)."""
+def write_jpeg_split(root, n, rank=0, world=1):
+    """n synthetic 512x512 pairs as UDIS-D lays them out: <root>/testing/input{1,2}/%06d.jpg (quality 95); with several ranks every
+    rank writes the files i = rank (mod world)."""
     import numpy as np
     from PIL import Image
     from stitch_amd.data import structured_pair
     for d in ("input1", "input2"):
         os.makedirs(os.path.join(root, "testing", d), exist_ok=True)
     base = [structured_pair(512, 512, seed=40 + i) for i in range(8)]         # 8 distinct scenes, rolled to n distinct pairs
-    for i in range(n):
+    for i in range(rank, n, world):
         a, b = base[i % 8]
         for d, t in (("input1", a), ("input2", b)):
             arr = np.roll(t[0].permute(1, 2, 0).numpy().astype(np.uint8), (3 * (i // 8), -5 * (i // 8)), (0, 1))
@@ -246,7 +247,9 @@ def harness_eval(model, args, rank, world, dist, log):
     root = os.path.join(tempfile.gettempdir(), f"stitch_bench_udis_{os.environ.get('MASTER_PORT', 'single')}_{n}")
     if rank == 0:
         shutil.rmtree(root, ignore_errors=True)
-        write_jpeg_split(root, n)
+    if dist:
+        dist.barrier()
+    write_jpeg_split(root, n, rank, world)              # (every rank encodes its own share of the files)
     if dist:
         dist.barrier()
     try:

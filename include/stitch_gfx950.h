@@ -139,7 +139,7 @@ int st_abi_chain_desc_size(void);
  * caller folds gamma / beta into w1 / b1.  w1 [hidden, 128], w2 [128, hidden] row-major contiguous; b1 [hidden], b2 [128];
  * hidden % 32 == 0, 32..2048; every pointer 16-byte aligned; out must not alias a.  fc1 + GELU are bit-identical to
  * st_conv_gemm(act = gelu); fc2 sums its `hidden` products in one chain (st_conv_gemm folds every 256 k): same products, the
- * last bits of the sum differ.  plan4[0] = 6; reported to the observer as M x 2 hidden x 128.                                 */
+ * last bits of the sum differ.  plan4[0] = 6; reported to the observer as M x (2 hidden [+ 128 with wp]) x 128.                 */
 typedef struct st_mlp_desc {
     const float* a;        /* [M, lda], 128 columns used: input and first residual                                         */
     float* out;            /* [M, ldo]                                                                                    */
@@ -151,6 +151,13 @@ typedef struct st_mlp_desc {
     int32_t lda, ldo, ld_res, M, hidden, ln;
     float ln_eps;
     int32_t reserved;      /* must be 0                                                                                   */
+    /* optional leading layer, the Block's attention output projection + residual (twins.py:622-623, 676-677, 790):
+     *   x = a . wp^T + bp + res0   takes a's place above (a is then the attention output, x never reaches HBM as a tensor of
+     * its own: it is parked in the block's rows of `out` and re-read as the MLP's residual).  wp [128,128]; NULL = absent.   */
+    const float* wp;
+    const float* bp;
+    const float* res0;     /* [M, ld_res0] or NULL; must not alias out                                                    */
+    int32_t ld_res0, reserved1;
 } st_mlp_desc;
 int st_mlp128(const st_mlp_desc* desc, void* stream);
 int st_abi_mlp_desc_size(void);

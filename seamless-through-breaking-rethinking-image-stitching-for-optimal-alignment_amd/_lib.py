@@ -55,7 +55,8 @@ class ChainDesc(C.Structure):
 class MlpDesc(C.Structure):
     """Mirror of ``st_mlp_desc``."""
     _fields_ = ([(n, C.c_void_p) for n in ("a", "out", "w1", "b1", "w2", "b2", "res")]
-                + [(n, C.c_int32) for n in ("lda", "ldo", "ld_res", "M", "hidden", "ln")] + [("ln_eps", C.c_float), ("reserved", C.c_int32)])
+                + [(n, C.c_int32) for n in ("lda", "ldo", "ld_res", "M", "hidden", "ln")] + [("ln_eps", C.c_float), ("reserved", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("wp", "bp", "res0")] + [("ld_res0", C.c_int32), ("reserved1", C.c_int32)])
 
 
 def declared_functions(header=HEADER):

@@ -1220,6 +1220,7 @@ extern "C" int st_linear_chain128(const st_chain_desc* desc, void* stream) {
 // fc2 accumulates its 512 k in ONE chain (the unfused kernels fold at k = 256; holding that fold would need 64 more registers
 // per lane than two waves per SIMD have) -- same products, the sum differs in the last bits.
 #define MLP_NW 4
+template <bool PROJ>
 __global__ __launch_bounds__(256, 2) void rowmlp128_kernel(const st_mlp_desc d) {
     constexpr int NJ = 16, NW = MLP_NW, STAGE = 2 * 32 * 128;   // floats per ring stage: [W1 chunk 32 x 128 | W2 slice 128 x 32]
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -1229,28 +1230,45 @@ __global__ __launch_bounds__(256, 2) void rowmlp128_kernel(const st_mlp_desc d) 
     const int G = (int)gridDim.x;
     const int blk0 = (int)blockIdx.x * NW;
     const int rounds = blk0 < nblk ? (nblk - blk0 + G * NW - 1) / (G * NW) : 0;
-    const int nhc = d.hidden >> 5, total = rounds * nhc;
+    // optional leading layer (the attention output projection of the Block, twins.py:622-623 / 676-677): x = a . wp^T + bp + res0,
+    // four more steps of 32 output features each in front of the hidden chunks; x then takes a's place
+    constexpr bool proj = PROJ;
+    const int npre = proj ? 4 : 0;
+    const int nhc = d.hidden >> 5, spr = npre + nhc, total = rounds * spr;
     if (total == 0) return;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
     const i32x4 rs1 = make_rsrc(d.w1, (unsigned)d.hidden * 128u * 4u), rs2 = make_rsrc(d.w2, 128u * (unsigned)d.hidden * 4u);
+    const i32x4 rsp = make_rsrc(proj ? d.wp : d.w1, 128u * 128u * 4u);
 
-    // step q = hidden chunk hc = q % nhc -> ring stage q & 1.  W1 chunk: 16 pieces of 1 KiB = two 512-B rows, slot s of row r holds
-    // k-chunk s ^ (r & 15) (rowchain128's image).  W2 slice: 16 pieces of 1 KiB = eight 128-B rows, slot s of row r holds k-chunk
-    // s ^ ((r >> 1) & 7) (conv_gemm_dma's image).  The swizzles are applied on the source side; 8 pieces per wave and step.
+    // step q = step s = q % spr of a round -> ring stage q & 1.  s < npre: chunk s of wp (image of a W1 chunk); otherwise hidden chunk
+    // hc = s - npre.  W1 chunk: 16 pieces of 1 KiB = two 512-B rows, slot t of row r holds k-chunk t ^ (r & 15) (rowchain128's image).
+    // W2 slice: 16 pieces of 1 KiB = eight 128-B rows, slot t of row r holds k-chunk t ^ ((r >> 1) & 7) (conv_gemm_dma's image).
+    // The swizzles are applied on the source side; 8 (4 for a wp step) pieces per wave and step.
     auto dma_step = [&](int q) {
-        const int hc = q % nhc;
+        const int s = __builtin_amdgcn_readfirstlane(q % spr);
+        const bool pre = PROJ && s < npre;
+        const int hc = pre ? s : s - npre;
         const unsigned st = lds0 + (unsigned)((q & 1) * STAGE * 4);
+        if (pre) {                                              // (a scalar branch: the descriptor operand of the DMA must be an SGPR quad)
 #pragma unroll
-        for (int u = 0; u < 16 / NW; ++u) {
-            const int p = wave * (16 / NW) + u, r = 2 * p + (lane >> 5);
-            const unsigned voff = (unsigned)((((hc << 5) + r) * 128 + (((lane & 31) ^ (r & 15)) << 2)) * 4);
-            lds_dma16(rs1, st + (unsigned)(p * 1024), voff, 0u);
+            for (int u = 0; u < 16 / NW; ++u) {
+                const int p = wave * (16 / NW) + u, r = 2 * p + (lane >> 5);
+                lds_dma16(rsp, st + (unsigned)(p * 1024), (unsigned)((((hc << 5) + r) * 128 + (((lane & 31) ^ (r & 15)) << 2)) * 4), 0u);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16 / NW; ++u) {
+                const int p = wave * (16 / NW) + u, r = 2 * p + (lane >> 5);
+                lds_dma16(rs1, st + (unsigned)(p * 1024), (unsigned)((((hc << 5) + r) * 128 + (((lane & 31) ^ (r & 15)) << 2)) * 4), 0u);
+            }
         }
+        if (!pre) {
 #pragma unroll
-        for (int u = 0; u < 16 / NW; ++u) {
-            const int p = wave * (16 / NW) + u, r = 8 * p + (lane >> 3);
-            const unsigned voff = (unsigned)((r * d.hidden + (((lane & 7) ^ ((r >> 1) & 7)) << 2)) * 4);
-            lds_dma16(rs2, st + (unsigned)(32 * 128 * 4 + p * 1024), voff, (unsigned)(hc << 7));
+            for (int u = 0; u < 16 / NW; ++u) {
+                const int p = wave * (16 / NW) + u, r = 8 * p + (lane >> 3);
+                const unsigned voff = (unsigned)((r * d.hidden + (((lane & 7) ^ ((r >> 1) & 7)) << 2)) * 4);
+                lds_dma16(rs2, st + (unsigned)(32 * 128 * 4 + p * 1024), voff, (unsigned)(hc << 7));
+            }
         }
     };
     dma_step(0);
@@ -1261,68 +1279,117 @@ __global__ __launch_bounds__(256, 2) void rowmlp128_kernel(const st_mlp_desc d) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) goff[j] = li * 32 + (((2 * j + lh) ^ ((li >> 1) & 7)) << 2);
 
+    // one K = 128 product of the block with the 32-row weight chunk in ring stage (q & 1): TRANSPOSED (weights first), so lane (li, lh)
+    // ends up with row li's output features 8 jj + 4 lh + t of the chunk
     float4 a[NJ];
+    auto chunk128 = [&](const float* ws) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float4 b = *reinterpret_cast<const float4*>(ws + foff[0]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int jn = j + 1 < NJ ? j + 1 : j;
+            const float4 bn = *reinterpret_cast<const float4*>(ws + foff[jn & 7] + (jn >> 3) * 64);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[j].w, acc, 0, 0, 0);
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return acc;
+    };
+    auto step_sync = [&](int q) {
+        // step q's weights (DMA issued one step ago; steps 0 and 1 before the loop) are in the ring once every wave's pieces have
+        // landed; everyone is past step q - 1, whose stage step q + 1 may now overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (q > 0 && q + 1 < total) dma_step(q + 1);
+    };
+
+    const float* xres = proj ? d.out : d.a;                      // where the rows the MLP adds back live (x is parked in `out` when computed here)
+    const int ld_xres = proj ? d.ldo : d.lda;
     int q = 0;
     for (int rd = 0; rd < rounds; ++rd) {
         const int blk = blk0 + wave + rd * G * NW;
         const bool active = blk < nblk;                         // wave-uniform; idle waves still load weights and meet the barriers
         const int row = blk * 32 + li;
         const bool rok = active && row < d.M;
-        if (active) {
+        const size_t rowc = (size_t)(row < d.M ? row : d.M - 1);   // rows past M (last block only) read a valid row and are never stored:
+        if (active) {                                           // unconditional loads, no per-lane branches around them
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                a[j] = rok ? *reinterpret_cast<const float4*>(d.a + (size_t)row * d.lda + 8 * j + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d.ln) {                                         // LayerNorm without affine (gamma / beta are folded into w1 / b1): as rowchain128
-                float s = 0.f;
+            for (int j = 0; j < NJ; ++j) a[j] = *reinterpret_cast<const float4*>(d.a + rowc * d.lda + 8 * j + 4 * lh);
+        }
+        if (proj) {
+            // x = a . wp^T + bp + res0, 32 features per step, written straight to the block's rows of `out` and read back below: x is
+            // needed twice (as this MLP's input and as its residual) and holding both a and x in registers next to the accumulators
+            // does not fit two waves per SIMD (hipcc spilled 55 registers); the rows are L2-warm when they come back
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c, ++q) {
+                step_sync(q);
+                if (active) {
+                    // bias and residual of the 16 features this lane ends up holding: requested before the MFMAs, used after them
+                    float4 bv[4], ev[4];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) s += (a[j].x + a[j].y) + (a[j].z + a[j].w);
-                s += __shfl_xor(s, 32, 64);
-                const float mean = s * (1.0f / 128.0f);
-                float v = 0.f;
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int col = (c << 5) + 8 * jj + 4 * lh;
+                        // (wave-uniform conditions: scalar branches, no exec masking)
+                        bv[jj] = d.bp ? *reinterpret_cast<const float4*>(d.bp + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        ev[jj] = d.res0 ? *reinterpret_cast<const float4*>(d.res0 + rowc * d.ld_res0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    const f32x16 acc = chunk128(smem + (q & 1) * STAGE + li * 128);
+                    if (rok) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    a[j].x -= mean; a[j].y -= mean; a[j].z -= mean; a[j].w -= mean;
-                    v += (a[j].x * a[j].x + a[j].y * a[j].y) + (a[j].z * a[j].z + a[j].w * a[j].w);
+                        for (int jj = 0; jj < 4; ++jj) {
+                            // (acc + bias) + residual: the unfused epilogue's order
+                            *reinterpret_cast<float4*>(d.out + rowc * d.ldo + (c << 5) + 8 * jj + 4 * lh) =
+                                make_float4((acc[4 * jj] + bv[jj].x) + ev[jj].x, (acc[4 * jj + 1] + bv[jj].y) + ev[jj].y,
+                                            (acc[4 * jj + 2] + bv[jj].z) + ev[jj].z, (acc[4 * jj + 3] + bv[jj].w) + ev[jj].w);
+                        }
+                    }
                 }
-                v += __shfl_xor(v, 32, 64);
-                const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + d.ln_eps);
+            }
+            if (active) {
+                // the stores above are complete (written through to L2; the vector L1 does not allocate on a store, and these rows were
+                // never read by this CU before) -> read x back in the operand layout
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) { a[j].x *= rstd; a[j].y *= rstd; a[j].z *= rstd; a[j].w *= rstd; }
+                for (int j = 0; j < NJ; ++j) a[j] = *reinterpret_cast<const float4*>(d.out + rowc * d.ldo + 8 * j + 4 * lh);
             }
         }
+        if (active && d.ln) {                                   // LayerNorm without affine (gamma / beta are folded into w1 / b1): as rowchain128
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) s += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+            s += __shfl_xor(s, 32, 64);
+            const float mean = s * (1.0f / 128.0f);
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                a[j].x -= mean; a[j].y -= mean; a[j].z -= mean; a[j].w -= mean;
+                v += (a[j].x * a[j].x + a[j].y * a[j].y) + (a[j].z * a[j].z + a[j].w * a[j].w);
+            }
+            v += __shfl_xor(v, 32, 64);
+            const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + d.ln_eps);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { a[j].x *= rstd; a[j].y *= rstd; a[j].z *= rstd; a[j].w *= rstd; }
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // (keeps the 64 accumulator zeros below from being scheduled above the projection)
         f32x16 o[4];
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[oc][r] = 0.f;
         for (int hc = 0; hc < nhc; ++hc, ++q) {
-            // step q's weights (DMA issued one step ago) are in the ring once every wave's pieces have landed; everyone is past
-            // step q - 1, whose stage step q + 1 may now overwrite
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (q > 0 && q + 1 < total) dma_step(q + 1);
+            step_sync(q);
             if (active) {
-                const float* w1s = smem + (q & 1) * STAGE + li * 128;
                 const float* w2s = smem + (q & 1) * STAGE + 32 * 128;
                 float4 bv[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) bv[jj] = *reinterpret_cast<const float4*>(d.b1 + (hc << 5) + 8 * jj + 4 * lh);
                 // ---- stage A: hidden chunk, K = 128
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                float4 b = *reinterpret_cast<const float4*>(w1s + foff[0]);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int jn = j + 1 < NJ ? j + 1 : j;
-                    const float4 bn = *reinterpret_cast<const float4*>(w1s + foff[jn & 7] + (jn >> 3) * 64);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[j].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[j].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[j].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[j].w, acc, 0, 0, 0);
-                    b = bn;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                const f32x16 acc = chunk128(smem + (q & 1) * STAGE + li * 128);
                 // first W2 fragments of stage B are requested before the GELU arithmetic
                 float4 g[4];
 #pragma unroll
@@ -1356,21 +1423,25 @@ __global__ __launch_bounds__(256, 2) void rowmlp128_kernel(const st_mlp_desc d) 
             }
         }
         if (rok) {
-            // out = (fc2 + b2) + x [+ res]: the unfused epilogue's order (fma(acc, 1, bias), + aux0, + aux1)
+            // out = (fc2 + b2) + x [+ res]: the unfused epilogue's order (fma(acc, 1, bias), + aux0, + aux1).  The pointer is laundered
+            // per round: b2's 16 loads are invariant across the rounds loop and hipcc otherwise hoists them to the top of the kernel,
+            // where they hold 64 registers for its whole length (the projection variant then spilled 55)
+            const float* b2p = d.b2;
+            asm volatile("" : "+s"(b2p));
 #pragma unroll
             for (int oc = 0; oc < 4; ++oc)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int col = oc * 32 + 8 * jj + 4 * lh;
-                    const float4 bb = *reinterpret_cast<const float4*>(d.b2 + col);
-                    const float4 x = *reinterpret_cast<const float4*>(d.a + (size_t)row * d.lda + col);
+                    const float4 bb = *reinterpret_cast<const float4*>(b2p + col);
+                    const float4 x = *reinterpret_cast<const float4*>(xres + rowc * ld_xres + col);
                     float4 v = make_float4((o[oc][4 * jj] + bb.x) + x.x, (o[oc][4 * jj + 1] + bb.y) + x.y, (o[oc][4 * jj + 2] + bb.z) + x.z,
                                            (o[oc][4 * jj + 3] + bb.w) + x.w);
                     if (d.res) {
-                        const float4 e = *reinterpret_cast<const float4*>(d.res + (size_t)row * d.ld_res + col);
+                        const float4 e = *reinterpret_cast<const float4*>(d.res + rowc * d.ld_res + col);
                         v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
                     }
-                    *reinterpret_cast<float4*>(d.out + (size_t)row * d.ldo + col) = v;
+                    *reinterpret_cast<float4*>(d.out + rowc * d.ldo + col) = v;
                 }
         }
     }
@@ -1387,23 +1458,27 @@ extern "C" int st_mlp128(const st_mlp_desc* desc, void* stream) {
     if ((((uintptr_t)d.a | (uintptr_t)d.out | (uintptr_t)d.w1 | (uintptr_t)d.b1 | (uintptr_t)d.w2 | (uintptr_t)d.b2) & 15)) return ST_EINVAL;
     if (d.res && (d.ld_res < 128 || (d.ld_res & 3) || ((uintptr_t)d.res & 15))) return ST_EINVAL;
     if (d.a == d.out) return ST_EINVAL;                        // the residual x is re-read at the end of a block: not in place
+    if (d.wp && (((uintptr_t)d.wp & 15) || (d.bp && ((uintptr_t)d.bp & 15)))) return ST_EINVAL;
+    if (!d.wp && (d.bp || d.res0)) return ST_EINVAL;           // bias / residual of a projection that is not there
+    if (d.res0 && (d.ld_res0 < 128 || (d.ld_res0 & 3) || ((uintptr_t)d.res0 & 15) || d.res0 == d.out)) return ST_EINVAL;
     const int nblk = (d.M + 31) / 32;
     int G = (nblk + MLP_NW - 1) / MLP_NW;
     if (G > 512) G = 512;                                       // two workgroups per CU
     const size_t lds = (size_t)(2 * 2 * 32 * 128) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)rowmlp128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = d.wp ? rowmlp128_kernel<true> : rowmlp128_kernel<false>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // the profiling observer sees the MLP as one launch of the family: M x (2 * hidden) x 128 = its FLOPs (2 M 128 hidden per product)
     st_gemm_observer_fn obs = g_observer;
     st_gemm_desc od;
     if (obs) {
         memset(&od, 0, sizeof(od));
         od.a = d.a; od.c = d.out; od.w = d.w1;
-        od.M = d.M; od.N = 2 * d.hidden; od.K = 128; od.H = 1; od.W = d.M; od.Cin = 128; od.ldx = d.lda; od.ldc = d.ldo; od.ldw = 128;
+        od.M = d.M; od.N = 2 * d.hidden + (d.wp ? 128 : 0); od.K = 128; od.H = 1; od.W = d.M; od.Cin = 128; od.ldx = d.lda; od.ldc = d.ldo; od.ldw = 128;
         od.kh = od.kw = od.sh = od.sw = 1; od.Ho = 1; od.Wo = d.M; od.batch = 1; od.alpha = 1.f;
         obs(&od, stream, 0, g_observer_user);
     }
     g_last_plan[0] = 6; g_last_plan[1] = 31; g_last_plan[2] = 1; g_last_plan[3] = 1;
-    hipLaunchKernelGGL(rowmlp128_kernel, dim3(G), dim3(64 * MLP_NW), lds, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(64 * MLP_NW), lds, (hipStream_t)stream, d);
     if (obs) obs(&od, stream, 1, g_observer_user);
     ST_CHECK_LAUNCH();
     return ST_OK;

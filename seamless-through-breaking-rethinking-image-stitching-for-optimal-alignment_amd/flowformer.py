@@ -32,6 +32,7 @@ from .homography import pack_conv
 FUSE_LN = os.environ.get("ST_FUSE_LN", "1") != "0"
 PAIR_CONVS = os.environ.get("ST_PAIR_CONVS", "1") != "0"       # convc2 + convf2 of the motion encoder as one launch
 FUSE_MLP = os.environ.get("ST_FUSE_MLP", "1") != "0"            # the C = 128 Twins MLPs (LN -> fc1 + GELU -> fc2 + residual) as one st_mlp128 launch
+FUSE_PROJ = os.environ.get("ST_FUSE_PROJ", "1") != "0"          # ... with the Block's attention output projection + residual in front, same launch
 FUSE_CHAIN = os.environ.get("ST_FUSE_CHAIN", "1") != "0"        # the latent layers' 128-wide tails as one st_linear_chain128 launch
 
 
@@ -211,7 +212,17 @@ class FlowFormer(ParamTree):
 
     # ================================================================== shared blocks
     @staticmethod
-    def _mlp(x, n2, fc1, fc2, eps, out=None, fc1_ln=None, extra_res=None):
+    def _mlp(x, n2, fc1, fc2, eps, out=None, fc1_ln=None, extra_res=None, proj=None):
+        """x + fc2(GELU(fc1(LN(x)))) [+ extra_res] (timm Mlp inside Block, twins.py:785-790).  proj = (att, (w, b), res): x is the Block's
+        attention branch x = att @ w^T + b + res (twins.py:622-623 / 676-677), computed by the same launch when the rows are 128 wide."""
+        if proj is not None:
+            att, (pw, pb), pres = proj
+            dev = att.device
+            if fc1_ln is not None and FUSE_LN and FUSE_MLP and FUSE_PROJ and att.shape[1] == 128 and pw.is_contiguous():
+                o = _new(att.shape[0], 128, dev) if out is None else out
+                return ops.mlp128(att, o, fc1_ln[0], fc1_ln[1], fc2[0], fc2[1], ln_eps=eps, res=extra_res, proj=(pw, pb, pres))
+            x = _new(att.shape[0], att.shape[1], dev)
+            ops.conv_gemm(att, pw, x, bias=pb, aux0=pres)
         dev = x.device
         if fc1_ln is not None and FUSE_LN and FUSE_MLP and x.shape[1] == 128 and fc2[0].is_contiguous() and fc1_ln[0].is_contiguous():
             o = _new(x.shape[0], 128, dev) if out is None else out
@@ -255,9 +266,7 @@ class FlowFormer(ParamTree):
             att = _new(N, C, dev)
             ops.window_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], H * W * 3 * C, 3 * C, *L["pads"], att,
                                  H * W * C, C, B, H, W, hd, C // hd, 7, (C // hd) ** -0.5)
-            x1 = _new(N, C, dev)
-            ops.conv_gemm(att, L["proj"][0], x1, bias=L["proj"][1], aux0=x)
-            x2 = self._mlp(x1, L["n2"], L["fc1"], L["fc2"], 1e-6, fc1_ln=L.get("fc1_ln"))
+            x2 = self._mlp(None, L["n2"], L["fc1"], L["fc2"], 1e-6, fc1_ln=L.get("fc1_ln"), proj=(att, L["proj"], x))
             # ---- PEG (twins.py:793-808)
             x3 = _new(N, C, dev)
             ops.dwconv3x3_residual(x2, t[f"peg{s}"][0], t[f"peg{s}"][1], x3, B, H, W, C)
@@ -276,9 +285,7 @@ class FlowFormer(ParamTree):
             ops.conv_gemm(xsn, Gk["kv"][0], kv, bias=Gk["kv"][1])
             ops.attention_kvlds(q, (H * W * C, C), kv[:, :C], (Nk * 2 * C, 2 * C), kv[:, C:], (Nk * 2 * C, 2 * C), att,
                                 (H * W * C, C), B, hd, H * W, Nk, C // hd, (C // hd) ** -0.5)
-            x4 = _new(N, C, dev)
-            ops.conv_gemm(att, Gk["proj"][0], x4, bias=Gk["proj"][1], aux0=x3)
-            x = self._mlp(x4, Gk["n2"], Gk["fc1"], Gk["fc2"], 1e-6, fc1_ln=Gk.get("fc1_ln"))
+            x = self._mlp(None, Gk["n2"], Gk["fc1"], Gk["fc2"], 1e-6, fc1_ln=Gk.get("fc1_ln"), proj=(att, Gk["proj"], x3))
         return x, H, W
 
     # ------------------------------------------------------------------ cost-volume encoder
@@ -409,9 +416,7 @@ class FlowFormer(ParamTree):
             sl = slice(b * N * nl, (b + 1) * N * nl)
             ops.window_attention(q[sl], k[sl], v[sl], 3 * C, nl * 3 * C, qp, kp, vp, att[sl], C, nl * C, nl, H1, W1, 8, 16, 7,
                                  16 ** -0.5)
-        x1 = _new(R, C, dev)
-        ops.conv_gemm(att, V["lproj"][0], x1, bias=V["lproj"][1], aux0=x)
-        x2 = self._mlp(x1, V["ln2"], V["lfc1"], V["lfc2"], 1e-5, fc1_ln=V["lfc1_ln"])
+        x2 = self._mlp(None, V["ln2"], V["lfc1"], V["lfc2"], 1e-5, fc1_ln=V["lfc1_ln"], proj=(att, V["lproj"], x))
         # ---------------- global block
         ops.layernorm(x2, V["gn1"][0], V["gn1"][1], y, 1e-5)
         z = _new(B * N, Cq, dev)
@@ -451,9 +456,7 @@ class FlowFormer(ParamTree):
             kb = kv[b * Nk:]
             ops.attention_kvlds(q[sl], (C, nl * C), kb[:, :C], (B * Nk * 2 * C, 2 * C), kb[:, C:], (B * Nk * 2 * C, 2 * C),
                                 att[sl], (C, nl * C), nl, 8, N, Nk, 16, 16 ** -0.5)
-        x3 = _new(R, C, dev)
-        ops.conv_gemm(att, V["gproj"][0], x3, bias=V["gproj"][1], aux0=x2)
-        return self._mlp(x3, V["gn2"], V["gfc1"], V["gfc2"], 1e-5, fc1_ln=V["gfc1_ln"], extra_res=extra_res)
+        return self._mlp(None, V["gn2"], V["gfc1"], V["gfc2"], 1e-5, fc1_ln=V["gfc1_ln"], extra_res=extra_res, proj=(att, V["gproj"], x2))
 
     def _cost_encoder(self, cost_maps, ctx, B, H1, W1):
         """CostPerceiverEncoder.forward (encoder.py:258-287) -> cost memory rows [B*N*8, 128]."""

@@ -182,9 +182,10 @@ def linear_chain128(a, out, layers):
     return out
 
 
-def mlp128(a, out, w1, b1, w2, b2, ln_eps=None, res=None):
-    """out = a + (GELU(LN(a) @ w1^T + b1) @ w2^T + b2) [+ res] over the 128-wide rows of ``a`` in one launch (st_mlp128: the hidden
-    activations stay on the CU).  ln_eps None = no LayerNorm (otherwise without affine: fold gamma / beta into w1 / b1)."""
+def mlp128(a, out, w1, b1, w2, b2, ln_eps=None, res=None, proj=None):
+    """out = x + (GELU(LN(x) @ w1^T + b1) @ w2^T + b2) [+ res] over 128-wide rows in one launch (st_mlp128: the hidden activations stay
+    on the CU).  x = a, or with proj = (wp [128,128], bp or None, res0 or None): x = a @ wp^T + bp + res0 (the Block's attention output
+    projection + residual in the same launch).  ln_eps None = no LayerNorm (otherwise without affine: fold gamma / beta into w1 / b1)."""
     hidden = w1.shape[0]
     assert w1.shape == (hidden, 128) and w2.shape == (128, hidden) and w1.is_contiguous() and w2.is_contiguous()
     assert b1.shape == (hidden,) and b2.shape == (128,) and a.shape[1] == 128 and out.shape == a.shape
@@ -195,6 +196,15 @@ def mlp128(a, out, w1, b1, w2, b2, ln_eps=None, res=None):
     if res is not None:
         assert res.shape == a.shape
         d.res, d.ld_res = res.data_ptr(), _ld(res)
+    if proj is not None:
+        wp, bp, res0 = proj
+        assert wp.shape == (128, 128) and wp.is_contiguous()
+        d.wp = wp.data_ptr()
+        if bp is not None:
+            d.bp = bp.data_ptr()
+        if res0 is not None:
+            assert res0.shape == a.shape
+            d.res0, d.ld_res0 = res0.data_ptr(), _ld(res0)
     check(lib.st_mlp128(C.byref(d), _stream()), "st_mlp128")
     return out
 

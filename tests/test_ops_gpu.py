@@ -830,6 +830,19 @@ def test_mlp128_fused(ops, M, hidden):
     ref2 = F.linear(F.gelu(F.linear(xd, w1.double(), b1.double())), w2.double(), b2.double()) + xd + extra.double()
     assert (o2.cpu().double() - ref2).abs().max() / ref2.abs().max() < 6e-6
     assert (o2 - o2u).abs().max().item() / scale < 1e-6
+    # the Block's attention output projection + residual in front (twins.py:622-623): x = att @ wp^T + bp + x0 inside the same launch
+    att, x0 = torch.randn(M, 128, generator=gg), torch.randn(M, 128, generator=gg)
+    wp, bp = torch.randn(128, 128, generator=gg) / 128 ** 0.5, torch.randn(128, generator=gg) * 0.1
+    xu, o3, o3u = (torch.empty(M, 128, device="cuda") for _ in range(3))
+    ops.conv_gemm(dev(att), dev(wp), xu, bias=dev(bp), aux0=dev(x0))
+    ops.mlp128(xu, o3u, w1f, b1f, dev(w2), dev(b2), ln_eps=1e-6, res=dev(extra))
+    ops.mlp128(dev(att), o3, w1f, b1f, dev(w2), dev(b2), ln_eps=1e-6, res=dev(extra), proj=(dev(wp), dev(bp), dev(x0)))
+    assert torch.equal(o3, o3u)                              # same products, same order: the same bits as projection launch + MLP launch
+    o4, o4u = torch.empty(M, 128, device="cuda"), torch.empty(M, 128, device="cuda")
+    ops.conv_gemm(dev(att), dev(wp), xu)                     # no bias, no residual
+    ops.mlp128(xu, o4u, dev(w1), dev(b1), dev(w2), dev(b2))
+    ops.mlp128(dev(att), o4, dev(w1), dev(b1), dev(w2), dev(b2), proj=(dev(wp), None, None))
+    assert torch.equal(o4, o4u)
     if M == 96:
         with pytest.raises(ops.StitchErrorBase):
             xc = dev(x)

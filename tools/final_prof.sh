@@ -1,19 +1,33 @@
 #!/bin/bash
-# final measurement pass of the round (GPU box, repo root): bench lines + rocprof kernel stats + per-shape table with PMC traffic
+# final measurement pass of the round (GPU box, repo root): bash tools/final_prof.sh [TAG=r4]
+# bench lines (configs[1] with the product harness, configs[2], configs[3], 2-rank gloo rehearsal) + rocprof kernel stats of the same
+# command + trace overlap + per-shape table with PMC traffic + SQ counters of the fused MLP kernel.  Everything lands under gpurun_out/;
+# copy what is to be judged into profiles/.
 export TMPDIR=/tmp
+TAG=${1:-r4}
 set -x
-python bench.py --batch 8 --streams 2 --steps 30 --warmup 4 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/r3_bench_batch8.json
-python bench.py --workload 1024 --steps 60 --warmup 8 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/r3_bench_1024.json
+python bench.py --no-cpu-baseline 2>gpurun_out/${TAG}_bench.err | grep '^{' > gpurun_out/${TAG}_bench_nocpu.json
+python bench.py --batch 8 --streams 2 --steps 30 --warmup 4 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_batch8.json
+python bench.py --workload 1024 --steps 60 --warmup 8 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_1024.json
+python bench.py --gpus 2 --backend gloo --share-gpu --steps 40 --warmup 6 --no-cpu-baseline --no-corr-roofline --harness-pairs 48 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_2rank_gloo_share_gpu.json
 rm -rf gpurun_out/prof_final
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o p -- python3 bench.py --no-cpu-baseline --no-corr-roofline > gpurun_out/prof_final.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o p -- python3 bench.py --no-cpu-baseline --no-corr-roofline --harness none > gpurun_out/prof_final.log 2>&1
 S=$(find gpurun_out/prof_final -name "*kernel_stats.csv" | head -1)
-cp $S gpurun_out/r3_bench_kernel_stats.csv
+cp $S gpurun_out/${TAG}_bench_kernel_stats.csv
 python tools/kernel_stats_summary.py $S $(python - <<PY
 import csv
 rows=list(csv.DictReader(open("$S")))
 print(next(int(r["Calls"]) for r in rows if "flow_warp_kernel" in r["Name"]))
 PY
-) gpurun_out/r3_kernel_summary.json > gpurun_out/r3_kernel_summary.txt
-python tools/trace_overlap.py $(find gpurun_out/prof_final -name "*kernel_trace.csv" | head -1) > gpurun_out/r3_trace_overlap.txt
-tail -3 gpurun_out/r3_kernel_summary.txt
-bash tools/run_pmc_shapes.sh
+) gpurun_out/${TAG}_kernel_summary.json > gpurun_out/${TAG}_kernel_summary.txt
+python tools/trace_overlap.py $(find gpurun_out/prof_final -name "*kernel_trace.csv" | head -1) > gpurun_out/${TAG}_trace_overlap.txt
+tail -3 gpurun_out/${TAG}_kernel_summary.txt
+bash tools/run_pmc_shapes.sh $TAG
+bash tools/mlp_pmc.sh > /dev/null 2>&1
+tail -4 gpurun_out/${TAG}_rowmlp_sq_counters.txt
+python bench.py 2>>gpurun_out/${TAG}_bench.err | grep '^{' > gpurun_out/${TAG}_bench.json
+python -c "
+import json
+for f in ('${TAG}_bench', '${TAG}_bench_batch8', '${TAG}_bench_1024', '${TAG}_bench_2rank_gloo_share_gpu'):
+    d = json.load(open('gpurun_out/' + f + '.json')); print(f, round(d['value'], 2), d.get('harness_pairs_per_s'), d.get('value_1_in_flight'), round(d['roofline']['frac'], 4))
+"

@@ -24,5 +24,5 @@ if len(sys.argv) > 3:          # python tools/kernel_stats_summary.py STATS.csv 
     import json
     json.dump(dict(forwards=fw, total_kernel_ms_per_forward=tot, gemm_family_ms_per_forward=gemm, other_kernels_ms_per_forward=tot - gemm,
                    source="rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-corr-roofline (kernel tracing serialises "
-                          "the dispatches of the three streams -- tools/trace_overlap.py on the same trace, profiles/r3_trace_overlap.txt: one kernel "
+                          "the dispatches of the three streams -- tools/trace_overlap.py on the same trace, profiles/r4_trace_overlap.txt: one kernel "
                           "resident 93 % of the time, two 1 % -- so these are STAND-ALONE kernel durations; the timed region runs them overlapped)"), open(sys.argv[3], "w"), indent=1)

@@ -22,6 +22,16 @@ for M in (65536, 32768, 524288):
         ops.conv_gemm(h, w2, o, bias=b2, aux0=x)
     def fused():
         ops.mlp128(x, o2, w1, b1, w2, b2, ln_eps=1e-6)
+    att, x0 = torch.randn(M, 128, device="cuda"), torch.randn(M, 128, device="cuda")
+    wp, bp = torch.randn(128, 128, device="cuda") / 11, torch.randn(128, device="cuda") * 0.1
+    xb, o3 = torch.empty(M, 128, device="cuda"), torch.empty(M, 128, device="cuda")
+    def proj_then_fused():
+        ops.conv_gemm(att, wp, xb, bias=bp, aux0=x0)
+        ops.mlp128(xb, o2, w1, b1, w2, b2, ln_eps=1e-6)
+    def proj_fused():
+        ops.mlp128(att, o3, w1, b1, w2, b2, ln_eps=1e-6, proj=(wp, bp, x0))
+    tp, tpf = run(proj_then_fused), run(proj_fused)
+    print(f"M={M}: projection launch + fused MLP {tp:.1f} us | projection inside the MLP launch {tpf:.1f} us | equal {torch.equal(o2, o3)}")
     tu, tf = run(unfused), run(fused)
     fl = 2.0 * M * 128 * 512 * 2
     print(f"M={M}: unfused {tu:.1f} us ({fl / tu / 1e6:.1f} TF/s) | fused {tf:.1f} us ({fl / tf / 1e6:.1f} TF/s = {fl / tf / 1e6 / 157.3:.3f} of peak) | max diff {(o - o2).abs().max().item():.2e}")
