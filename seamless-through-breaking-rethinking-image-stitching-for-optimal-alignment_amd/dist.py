@@ -21,6 +21,8 @@ def init(backend=None, expect_world=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if expect_world is not None and int(expect_world) != world:
         raise RuntimeError(f"launched with WORLD_SIZE={world} but {expect_world} ranks were requested")
+    if dist.is_initialized():
+        backend = dist.get_backend()         # the caller's process group decides (bench.py --backend gloo --share-gpu: every rank on cuda:0)
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     gpu = backend == "nccl"
     if gpu:

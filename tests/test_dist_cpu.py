@@ -4,6 +4,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
@@ -95,3 +97,25 @@ def test_init_refuses_a_world_size_mismatch(monkeypatch):
     with pytest.raises(RuntimeError):
         sd.init(backend="gloo", expect_world=8)
     assert sd.init(backend="gloo", expect_world=1) == (0, 1, int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def test_init_respects_an_existing_process_group(monkeypatch):
+    """`dist.init()` inside a process whose caller already initialised torch.distributed (bench.py's ranks) must take that group's
+    backend: with `--backend gloo --share-gpu` rank 1 has LOCAL_RANK = 1 on a 1-GPU box, and the one-process-per-GPU check of the
+    nccl path would kill it while rank 0 waits in the next collective (the hang of round 4's first 2-rank rehearsal)."""
+    import torch
+    import torch.distributed as tdist
+    from stitch_amd import dist as sdist
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "3")                       # more than the GPUs visible here (0) or on a 1-GPU box
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    tdist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert sdist.init() == (0, 1, 3)                        # no RuntimeError: the gloo group is CPU-side
+    finally:
+        tdist.destroy_process_group()
+    with pytest.raises(RuntimeError):
+        sdist.init()                                            # no group: the nccl default needs one GPU per rank

@@ -9,7 +9,6 @@ set -x
 python bench.py --no-cpu-baseline 2>gpurun_out/${TAG}_bench.err | grep '^{' > gpurun_out/${TAG}_bench_nocpu.json
 python bench.py --batch 8 --streams 2 --steps 30 --warmup 4 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_batch8.json
 python bench.py --workload 1024 --steps 60 --warmup 8 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_1024.json
-python bench.py --gpus 2 --backend gloo --share-gpu --steps 40 --warmup 6 --no-cpu-baseline --no-corr-roofline --harness-pairs 48 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_2rank_gloo_share_gpu.json
 rm -rf gpurun_out/prof_final
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o p -- python3 bench.py --no-cpu-baseline --no-corr-roofline --harness none > gpurun_out/prof_final.log 2>&1
 S=$(find gpurun_out/prof_final -name "*kernel_stats.csv" | head -1)
@@ -26,8 +25,12 @@ bash tools/run_pmc_shapes.sh $TAG
 bash tools/mlp_pmc.sh > /dev/null 2>&1
 tail -4 gpurun_out/${TAG}_rowmlp_sq_counters.txt
 python bench.py 2>>gpurun_out/${TAG}_bench.err | grep '^{' > gpurun_out/${TAG}_bench.json
+# 2-rank rehearsal of the launcher / sharding / all-gather on the 1-GPU box (both ranks on cuda:0, gloo): bounded, last
+timeout -k 10 300 python bench.py --gpus 2 --backend gloo --share-gpu --steps 40 --warmup 6 --no-cpu-baseline --no-corr-roofline --harness-pairs 48 2>gpurun_out/${TAG}_bench_2rank.err | grep '^{' > gpurun_out/${TAG}_bench_2rank_gloo_share_gpu.json
 python -c "
 import json
 for f in ('${TAG}_bench', '${TAG}_bench_batch8', '${TAG}_bench_1024', '${TAG}_bench_2rank_gloo_share_gpu'):
-    d = json.load(open('gpurun_out/' + f + '.json')); print(f, round(d['value'], 2), d.get('harness_pairs_per_s'), d.get('value_1_in_flight'), round(d['roofline']['frac'], 4))
+    try: d = json.load(open('gpurun_out/' + f + '.json'))
+    except Exception as e: print(f, 'missing', e); continue
+    print(f, round(d['value'], 2), d.get('harness_pairs_per_s'), d.get('value_1_in_flight'), round(d['roofline']['frac'], 4))
 "
