@@ -122,7 +122,7 @@ class EvalPipeline:
     Per pair the host (1) takes the decoded arrays from the worker pool, (2) copies them into the slot's pinned buffers, (3)
     enqueues the two H2D copies on a COPY stream of its own -- an H2D copy enqueued on the slot's compute stream would sit behind
     the slot's previous graph and the next graph behind the copy: measured 75.6 instead of 81.8 pairs/s
-    (tools/harness_profile2.py) -- and (4) on the slot's stream: wait for the copy, uint8 HWC -> float CHW into the graph's static
+    (a phase-timed copy of this loop, round 4; tools/harness_profile.py sweeps streams / decode threads) -- and (4) on the slot's stream: wait for the copy, uint8 HWC -> float CHW into the graph's static
     inputs, replay the graph, copy the (psnr, ssim) row into the device table.  At most two launches per slot are outstanding
     (the host waits on the completion event of the launch before the previous one), so the GPU always has work queued and the
     host never runs more than 2 k pairs ahead."""
