@@ -106,7 +106,7 @@ def test_corr_volume_vs_reference_golden(golden_ops):
     vol = torch.empty((B, H * W, H * W), device="cuda")
     stitch_amd.ops.corr_volume(r1, r2, vol)
     err = (vol.cpu().reshape(ref.shape) - ref).abs().max().item()
-    check("corr_out_rel", err / ref.abs().max().item(), 1e-6)      # measured 2.64e-07
+    check("corr_out_rel", err / ref.abs().max().item(), 8e-7)      # measured 2.64e-07
 
 
 def test_resnet_stage1_vs_reference_golden(model, golden_ops):

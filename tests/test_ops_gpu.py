@@ -812,7 +812,7 @@ def test_mlp128_fused(ops, M, hidden):
     out = torch.full((M, 136), 7.0, device="cuda")
     ops.mlp128(xw[:, 4:132], out[:, 4:132], w1f, b1f, dev(w2), dev(b2), ln_eps=1e-6)
     scale = ref.abs().max().item()
-    check(f"mlp128_vs_fp64_rel_{M}_{hidden}", (out[:, 4:132].cpu().double() - ref).abs().max() / scale, 1.6e-6)      # measured 3.5e-7 .. 5.1e-7
+    check(f"mlp128_vs_fp64_rel_{M}_{hidden}", (out[:, 4:132].cpu().double() - ref).abs().max() / scale, {512: 1.6e-6, 256: 1.1e-6, 32: 3.5e-7}[hidden])      # measured 5.1e-7 / 3.5e-7 / 1.1e-7 (hidden 512 / 256 / 32)
     assert (out[:, :4] == 7.0).all() and (out[:, 132:] == 7.0).all()
     # the unfused launches
     hu, ou = torch.empty(M, hidden, device="cuda"), torch.empty(M, 128, device="cuda")

@@ -218,6 +218,6 @@ def test_quality_psnr_ssim_vs_oracle(model, seeded_sd):
     check("quality_same_start_flow_max_px", ss["flow_max"], 6e-2, inclusive=True)
     # SSIM is dominated by the occlusion pixels that still flip (~100 of 262144 from an identical start, each one zeroes
     # a pixel inside 49 windows x 3 channels)
-    check("quality_same_start_d_psnr_db", ss["d_psnr"], 0.005, inclusive=True)
+    check("quality_same_start_d_psnr_db", ss["d_psnr"], 0.0012, inclusive=True)      # measured 3.7e-4 dB (north_star: 0.01)
     check("quality_same_start_d_ssim", ss["d_ssim"], 2e-3, inclusive=True)
     check("quality_same_start_occ_flips", ss["occ_flips"], 320, inclusive=True)      # measured 105

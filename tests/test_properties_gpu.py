@@ -109,8 +109,8 @@ def test_test_out_1024_vs_oracle(model, seeded_sd):
         assert o[k] == r[k], (k, o[k], r[k])
     assert tuple(o["blend_image"].shape) == tuple(r["blend_image"].shape) and o["blend_image"].dtype == torch.uint8
     d = (o["blend_image"].cpu().int() - r["blend_image"].int()).abs()
-    check("out1024_blend_gt2_frac", (d > 2).float().mean(), 1.5e-3)      # measured 0.000401
-    check("out1024_H_rel", (o["H"].cpu() - r["H"]).abs().max().item() / max(1.0, r["H"].abs().max().item()), 1e-6)      # measured 2.45e-07
+    check("out1024_blend_gt2_frac", (d > 2).float().mean(), 1.2e-3)      # measured 0.000401
+    check("out1024_H_rel", (o["H"].cpu() - r["H"]).abs().max().item() / max(1.0, r["H"].abs().max().item()), 7.5e-7)      # measured 2.45e-07
     flips = (o["mask1"].cpu() != r["mask1"]).float().mean()
     check("out1024_mask1_flip_frac", flips, 1e-5)      # measured 0
     occ = (o["occlusion_mask"].cpu() != r["occlusion_mask"]).float().mean()

@@ -76,7 +76,7 @@ def test_tps_solve_and_warp_vs_reference_golden(gold):
     ps, pd = T(gold["tps_ps"]), T(gold["tps_pd"])
     kw, aw = ops.tps2_solve(pd[0].cuda(), ps[0].cuda(), ps[0].cuda(), mode=0)     # get_tps_transform(points_dst, points_src)
     check("tps2_kw_rel", (kw.cpu() - T(gold["tps_kw"])[0]).abs().max().item() / max(1.0, np.abs(gold["tps_kw"]).max()), 2.5e-6)      # measured 7.15e-07
-    check("tps2_aw_abs", (aw.cpu() - T(gold["tps_aw"])[0]).abs().max(), 1e-6)      # measured 2.38e-07
+    check("tps2_aw_abs", (aw.cpu() - T(gold["tps_aw"])[0]).abs().max(), 7.5e-7)      # measured 2.38e-07
     out = ops.tps2_warp(img.cuda(), pd[0], ps[0], weights=(T(gold["tps_kw"])[0].cuda(), T(gold["tps_aw"])[0].cuda()))
     d = (out.cpu()[..., ::2, ::2] - T(gold["tps_warp_sub"])).abs()
     print(f"[tps2 warp, reference weights] max {d.max():.3e} p99 {np.percentile(d.numpy(), 99):.3e}")
@@ -171,9 +171,9 @@ def test_mix_methods_vs_oracle_and_reference_golden(tp, gold, mname):
           f"{da[:, -1].max():.1e}, blend: {(db > 0).float().mean():.2e} of bytes differ (max {int(db.max())})")
     check(f"mix_{mname}_mask2_flips", mflips, 2, inclusive=True)                    # measured 0
     assert da[:, -1].max() == 0                                    # the binary "left to the inpainter" mask is exact
-    check(f"mix_{mname}_output2_p99", np.percentile(d.numpy(), 99), 1.2e-2)         # measured 3.9e-3
+    check(f"mix_{mname}_output2_p99", np.percentile(d.numpy(), 99), {"all_img1_with_inpaint": 9.7e-3, "inpaint_all_area": 1.2e-2}[mname])         # measured 3.2e-3 / 3.9e-3
     check(f"mix_{mname}_blend_gt1_frac", (db > 1).float().mean(), 1e-4)           # measured 0
-    check(f"mix_{mname}_blend_differs_frac", (db > 0).float().mean(), 1.2e-3)     # measured 3.7e-4
+    check(f"mix_{mname}_blend_differs_frac", (db > 0).float().mean(), {"all_img1_with_inpaint": 1.2e-3, "inpaint_all_area": 8.4e-4}[mname])     # measured 3.7e-4 / 2.8e-4
 
 
 def test_mix_stage_kernels_bit_exact():
