@@ -1460,6 +1460,7 @@ extern "C" int st_mlp128(const st_mlp_desc* desc, void* stream) {
     if (d.a == d.out) return ST_EINVAL;                        // the residual x is re-read at the end of a block: not in place
     if (d.wp && (((uintptr_t)d.wp & 15) || (d.bp && ((uintptr_t)d.bp & 15)))) return ST_EINVAL;
     if (!d.wp && (d.bp || d.res0)) return ST_EINVAL;           // bias / residual of a projection that is not there
+    if (d.wp && d.res == d.out) return ST_EINVAL;              // with a projection the block's rows of `out` hold the parked x until the end
     if (d.res0 && (d.ld_res0 < 128 || (d.ld_res0 & 3) || ((uintptr_t)d.res0 & 15) || d.res0 == d.out)) return ST_EINVAL;
     const int nblk = (d.M + 31) / 32;
     int G = (nblk + MLP_NW - 1) / MLP_NW;
