@@ -211,7 +211,7 @@ def cpu_baseline_and_parity(model, ops):
                   "note": "numerical parity of the two implementations, NOT a quality figure: with the seeded random weights (no checkpoint offline) "
                           "the stitched images are ~12.4 dB from image 1 for both paths; the seeded flow network amplifies a ~1e-5 px difference of the "
                           "homography corner offsets ~1e4x, and the CPU oracle run from the HIP path's own offsets moves by the same flow / flip "
-                          "amounts (profiles/r3_parity.json: oracle_sensitivity); the enforceable criterion is the stage-held-fixed tests "
+                          "amounts (profiles/r4_parity.json: oracle_sensitivity); the enforceable criterion is the stage-held-fixed tests "
                           "(tests/test_parity_gpu.py).  Metric kernel = evaluate.py:44-65 restated from skimage 0.19's published algorithm "
                           "(skimage itself absent: parity vs skimage unpinned)"}
     finally:
