@@ -42,7 +42,7 @@ typedef struct st_gemm_desc {
     int32_t batch;         /* grid.z batches (0/1 = single)                                         */
     int64_t batch_stride_a, batch_stride_w, batch_stride_c;   /* in floats                          */
     int32_t tile_cfg;      /* 0 = auto; register-staged 1: 128x128, 2: 128x64, 3: 64x64, 4: 128x32;
-                              LDS-DMA pipelined (Cin % 32 == 0) 12: 128x64, 13: 64x64, 14: 128x32;
+                              LDS-DMA pipelined (Cin % 32 == 0) 12: 128x64, 13: 64x64, 14: 128x32, 15: 64x128 (never auto);
                               row-streaming (plain matrix, K = 64 / 128) 20 */
     int32_t split_k;       /* 0 = auto, 1 = off, >1 = K slices (needs workspace, batch <= 1)        */
     float* workspace;      /* split-K slabs [split_k, M, N] or NULL (then never split)              */

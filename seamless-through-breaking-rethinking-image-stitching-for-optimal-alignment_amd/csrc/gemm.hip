@@ -1863,12 +1863,15 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         const bool dma = dma_ok && d.K >= 128;
         if (d.N <= 32) cfg = dma ? 14 : 4;
         else cfg = dma ? 13 : 3;
+        // (64x128, tile_cfg 15, one workgroup per CU with two accumulator tiles per wave, stays selectable but is not chosen: round 4
+        // measured it equal on the real z|r launches (65.0 / 63.0 vs 64.0 / 63.4 us, tools/tile15_bench.py, bit-identical) and 0.8 % slower
+        // in the pipeline, 82.7 -> 82.0 pairs/s; it only wins on N = 256, K = 2304, a shape the path does not have)
     }
     if (cfg > 10 && !dma_ok) return ST_EINVAL;
     if ((d.a2 || d.c_t) && cfg <= 10) return ST_EINVAL;        // second A source / transposed copy: LDS-DMA kernels only
     // split-K: a launch that cannot fill the 256 CUs (M = 4096-pixel maps x 64..256 channels) is cut
     // along K into slabs reduced by a second tiny kernel (deterministic order; no atomics).
-    static const int bms[5] = {0, 128, 128, 64, 128}, bns[5] = {0, 128, 64, 64, 32};
+    static const int bms[6] = {0, 128, 128, 64, 128, 64}, bns[6] = {0, 128, 64, 64, 32, 128};
     const long tiles = cfg > 10 ? nwg(bms[cfg - 10], bns[cfg - 10]) : nwg(bms[cfg], bns[cfg]);
     int split = d.split_k;
     if (split == 0) {
@@ -1896,6 +1899,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     // was measured: kernels of different pairs overlap better (3-in-flight / 1-in-flight 1.18 instead of 1.135) but a tile then has ONE K
     // step to land and every kernel slows down: 71.9 -> 67.9 pairs/s with one pair in flight, 81.6 -> 80.2 with three)
     if (cfg == 13) return launch_dma<2, 2, 1, 1, 4>(d, s);
+    if (cfg == 15) return launch_dma<2, 2, 1, 2, 4>(d, s);      // 64x128: selectable only (see the tile choice above)
     if (cfg == 14) return launch_dma<4, 1, 1, 1, 4>(d, s);      // (80 KB of LDS; a 3-deep ring, 60 KB, measured neutral: PatchEmbed's 6x3 conv is not occupancy-bound)
     switch (cfg) {
         case 1: return launch_cfg<2, 2, 2, 2>(d, aligned, s);

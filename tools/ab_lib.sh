@@ -7,7 +7,7 @@ PKG=seamless-through-breaking-rethinking-image-stitching-for-optimal-alignment_a
 R=${1:-2}
 cp $PKG/libstitch_gfx950.so /tmp/new.so
 run() {
-  python bench.py --steps 80 --warmup 10 --no-cpu-baseline --no-corr-roofline 2>/dev/null | python -c "
+  python bench.py --steps 80 --warmup 10 --no-cpu-baseline --no-corr-roofline --harness none 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
