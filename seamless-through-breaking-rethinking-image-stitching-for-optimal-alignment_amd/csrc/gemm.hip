@@ -1864,8 +1864,8 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         if (d.N <= 32) cfg = dma ? 14 : 4;
         else cfg = dma ? 13 : 3;
         // (64x128, tile_cfg 15, one workgroup per CU with two accumulator tiles per wave, stays selectable but is not chosen: round 4
-        // measured it equal on the real z|r launches (65.0 / 63.0 vs 64.0 / 63.4 us, tools/tile15_bench.py, bit-identical) and 0.8 % slower
-        // in the pipeline, 82.7 -> 82.0 pairs/s; it only wins on N = 256, K = 2304, a shape the path does not have)
+        // measured it equal on the real z|r launches (67.0 / 65.3 vs 66.6 / 64.7 us, tools/tile15_bench.py, bit-identical) and 0.8 % slower
+        // in the pipeline, 82.7 -> 82.0 pairs/s; it wins 2-5 % only on plain N = 256 long-K convs, which the path does not have)
     }
     if (cfg > 10 && !dma_ok) return ST_EINVAL;
     if ((d.a2 || d.c_t) && cfg <= 10) return ST_EINVAL;        // second A source / transposed copy: LDS-DMA kernels only

@@ -13,6 +13,10 @@ def run(fn, iters=20):
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 B, H, W = 2, 64, 64
+# warm the chip first: the first shapes of an earlier version of this script read 10 us slower than the same launch measured last
+_x, _w, _c = torch.randn(8192, 1920, device="cuda"), torch.randn(256, 1920, device="cuda"), torch.empty(8192, 256, device="cuda")
+for _ in range(40):
+    run(lambda: ops.conv_gemm(_x, _w, _c, split_k=1), iters=50)
 for (Cin, Co, kh, kw, ph, pw, act) in [(384, 256, 1, 5, 0, 2, "sigmoid"), (384, 256, 5, 1, 2, 0, "sigmoid"), (128, 256, 3, 3, 1, 1, "relu"), (256, 128, 3, 3, 1, 1, "relu"),
                                       (384, 128, 1, 5, 0, 2, "tanh"), (256, 256, 3, 3, 1, 1, "relu")]:
     x = torch.randn(B * H * W, Cin, device="cuda"); w = torch.randn(Co, kh * kw * Cin, device="cuda") / (kh * kw * Cin) ** 0.5
