@@ -795,6 +795,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
             mfma_k(1, 1); mfma_k(1, 2); mfma_k(1, 3);
             if (STAGES != 4 && (t & (KBLK - 1)) == KBLK - 1 && t + 1 < ntiles) fold();    // (4-deep ring: folded by the callers, at block ends)
         };
+        // (round 4 measured ONE barrier per two K steps -- the ring used in stage pairs, an even tile issuing the whole next pair's DMA, the odd
+        // tile closing the pair with vmcnt(0) + s_barrier: bit-identical, 81.85 -> 81.65 pairs/s and 72.0 -> 71.2 with one pair in flight: what
+        // this loop waits for is the DMA's distance ahead (3 tiles here, 2 in the pair scheme), not the barrier itself)
         if (PERSIST) {
             for (int mt = 0; mt < nmt; ++mt) {
                 gemm_epilogue_load<TM, TN>(d, eop, (tile_m + mt * G) * BM, n0, wm, wn, li, lh, 1);   // lands under the MFMAs
