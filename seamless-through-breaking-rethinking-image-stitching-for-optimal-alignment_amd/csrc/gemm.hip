@@ -1900,7 +1900,8 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     if (cfg == 12) return launch_dma<2, 2, 2, 1, 4>(d, s);
     // (a 3-deep ring -- 48 KB, three workgroups per CU -- is correct with this body (the K-block fold is independent of the ring depth) and
     // was measured: kernels of different pairs overlap better (3-in-flight / 1-in-flight 1.18 instead of 1.135) but a tile then has ONE K
-    // step to land and every kernel slows down: 71.9 -> 67.9 pairs/s with one pair in flight, 81.6 -> 80.2 with three)
+    // step to land and every kernel slows down: 71.9 -> 67.9 pairs/s with one pair in flight, 81.6 -> 80.2 with three; a 5-deep ring
+    // -- 80 KB, four tiles ahead -- for the convs and K >= 1024, round 4: 82.65 -> 81.5 / 72.5 -> 71.6: two workgroups no longer share a CU)
     if (cfg == 13) return launch_dma<2, 2, 1, 1, 4>(d, s);
     if (cfg == 15) return launch_dma<2, 2, 1, 2, 4>(d, s);      // 64x128: selectable only (see the tile choice above)
     if (cfg == 14) return launch_dma<4, 1, 1, 1, 4>(d, s);      // (80 KB of LDS; a 3-deep ring, 60 KB, measured neutral: PatchEmbed's 6x3 conv is not occupancy-bound)
