@@ -792,7 +792,7 @@ def test_linear_chain128(ops, M):
     assert torch.equal(o2, ou)
 
 
-@pytest.mark.parametrize("M,hidden", [(2048, 512), (4099, 512), (96, 256), (17, 32)])
+@pytest.mark.parametrize("M,hidden", [(2048, 512), (4099, 512), (96, 256), (17, 32), (70001, 512)])      # 70001 rows: a wave walks two row blocks (grid capped at 512 workgroups)
 def test_mlp128_fused(ops, M, hidden):
     """st_mlp128: x + fc2(GELU(fc1(LN(x)))) [+ second residual] of the C = 128 Twins / vertical-layer MLPs (twins.py:785-790) in ONE
     launch, the hidden activations staying on the CU: against fp64 torch, against the unfused launches (fc1 + GELU bit-identical by
