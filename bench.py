@@ -301,7 +301,10 @@ def worker(args):
         import torch.distributed as dist
         if world != args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        from stitch_amd import dist as sdist
+        dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=sdist.timeout())
+        if os.environ.get("ST_BENCH_FAIL_RANK") == str(rank):        # tests/test_dist_cpu.py: one rank dies before the collective
+            raise RuntimeError("injected failure (ST_BENCH_FAIL_RANK)")
         vals = torch.full((args.steps,), float(rank))
         gathered = [torch.empty_like(vals) for _ in range(world)]
         dist.all_gather(gathered, vals)
@@ -321,7 +324,8 @@ def worker(args):
     if "RANK" in os.environ and "MASTER_PORT" in os.environ:      # launched by torch.distributed.run (also with 1 rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world,      # "nccl" is RCCL on ROCm
+        from stitch_amd import dist as sdist
+        dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=sdist.timeout(),     # "nccl" is RCCL on ROCm
                                 device_id=torch.device("cuda", local) if args.backend == "nccl" else None)
 
     import stitch_amd
@@ -504,7 +508,13 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args)          # parent: starts the N ranks as a child process, relays the JSON line
-    worker(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import stitch_amd                                  # noqa: F401  (package import for the guard only)
+        from stitch_amd import dist as sdist
+        with sdist.rank_guard("bench.py worker"):          # a failing rank leaves non-zero BEFORE its peers' next collective
+            worker(args)
+    else:
+        worker(args)
 
 
 if __name__ == "__main__":

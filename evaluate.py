@@ -54,4 +54,10 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import stitch_amd                                   # noqa: F401
+        from stitch_amd import dist as _sdist
+        with _sdist.rank_guard("evaluate.py"):
+            main()
+    else:
+        main()

@@ -311,4 +311,10 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import stitch_amd                                   # noqa: F401
+        from stitch_amd import dist as _sdist
+        with _sdist.rank_guard("out.py"):
+            main()
+    else:
+        main()

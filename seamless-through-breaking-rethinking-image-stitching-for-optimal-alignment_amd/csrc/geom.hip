@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict_
                 const float qx = sp[(c - 3) * 2], qy = sp[(c - 3) * 2 + 1];
                 const float d0 = 1.0f - 1.0f, dx = px - qx, dy = py - qy;
                 const float d2 = (d0 * d0 + dx * dx) + dy * dy;                 // sum over (1,x,y) components (:157)
-                v = d2 * logf(d2 + 1e-6f);
+                v = d2 * st_logf_cr(d2 + 1e-6f);
             } else v = tp[r * 2 + (c - n3)];
         } else {
             const int k = r - N;                                                // rows [0 | P^T]
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void tps_warp_kernel(const float* __restrict__
     for (int k = 0; k < N; ++k) {
         const float dx = gx - s_src[2 * k], dy = gy - s_src[2 * k + 1];
         const float d2 = dx * dx + dy * dy;
-        const float r = d2 * logf(d2 + 1e-6f);
+        const float r = d2 * st_logf_cr(d2 + 1e-6f);
         xs = __fmaf_rn(s_T[3 + k], r, xs); ys = __fmaf_rn(s_T[n3 + 3 + k], r, ys);
     }
     const Tap4 t = taps_from_normalised(xs, ys, W, H);

@@ -153,13 +153,13 @@ __device__ __forceinline__ float tps2_u(float ax, float ay, float bx, float by, 
     if (mode == 1) {
         const float dx = ax - bx, dy = ay - by;
         const float d2 = dx * dx + dy * dy;
-        return d2 * logf(d2 + 1.1920929e-7f);
+        return d2 * st_logf_cr(d2 + 1.1920929e-7f);
     }
     const float dot = __fmaf_rn(ay, by, ax * bx);                   // [N,2] @ [2,M]: torch's k = 2 contraction
     const float a2 = ax * ax + ay * ay, b2 = bx * bx + by * by;
     float d2 = (-2.0f * dot + a2) + b2;
     d2 = fmaxf(d2, 0.0f);
-    return 0.5f * d2 * logf(d2 + 1e-8f);
+    return 0.5f * d2 * st_logf_cr(d2 + 1e-8f);
 }
 
 // f(A_i) = rhs_i for f(v) = a0 + [ax ay].v + sum_j w_j U(v, Bp_j): L = [[K, P], [P^T, 0]], K_ij = U(A_i, Bp_j), P = [1, A],

@@ -3,13 +3,45 @@ collective; one all-gather (RCCL over xGMI on the GPU box, ``nccl`` backend) of 
 the end.  Replaces the reference's single-process ``nn.DataParallel`` (out.py:80, evaluate.py:119)."""
 from __future__ import annotations
 
+import contextlib
+import datetime
 import os
+import sys
+import traceback
 
 import torch
 import torch.distributed as dist
 
 
-def init(backend=None, expect_world=None):
+def timeout(seconds=None):
+    """Finite timeout of every process group this package (and bench.py / out.py) opens: ``ST_DIST_TIMEOUT_S`` or 600 s.
+    torch's defaults are 10 min (nccl) / 30 min (gloo); what matters is that it is FINITE and passed explicitly, so that a
+    rank waiting in a collective for a peer that died does not sit there for the rest of the job."""
+    if seconds is None:
+        seconds = float(os.environ.get("ST_DIST_TIMEOUT_S", "600"))
+    return datetime.timedelta(seconds=float(seconds))
+
+
+@contextlib.contextmanager
+def rank_guard(what="rank body"):
+    """Wrap one rank's body: an exception is logged WITH ITS RANK and the process leaves at once with a non-zero code
+    (``os._exit``: no destructors, no further collective) so that torchrun stops the peers instead of letting them wait in
+    their next collective (round 4's 2-rank hang: rank 1 raised before an all_gather rank 0 had already entered).  Peers not
+    under torchrun fall out of the collective after ``timeout()``."""
+    try:
+        yield
+    except BaseException as e:                      # SystemExit(0) passes through; everything else is fatal for the job
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        rank, world = os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1")
+        sys.stderr.write(f"[stitch_amd.dist] rank {rank}/{world} failed in {what}: {type(e).__name__}: {e}\n")
+        traceback.print_exc()
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(e.code if isinstance(e, SystemExit) and isinstance(e.code, int) else 1)
+
+
+def init(backend=None, expect_world=None, timeout_s=None):
     """Initialise torch.distributed from the torchrun environment; returns (rank, world_size, local_rank).
 
     With a GPU backend the process is bound to ITS GPU here (``torch.cuda.set_device(local_rank)`` and ``device_id=`` for the
@@ -32,7 +64,8 @@ def init(backend=None, expect_world=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local) if gpu else None)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout(timeout_s),
+                                device_id=torch.device("cuda", local) if gpu else None)
     if dist.is_initialized() and dist.get_world_size() != world:
         raise RuntimeError(f"process group has {dist.get_world_size()} ranks, environment says {world}")
     return rank, world, local

@@ -119,3 +119,67 @@ def test_init_respects_an_existing_process_group(monkeypatch):
         tdist.destroy_process_group()
     with pytest.raises(RuntimeError):
         sdist.init()                                            # no group: the nccl default needs one GPU per rank
+
+
+def test_failing_rank_stops_the_job_under_the_launcher():
+    """One rank raising before a collective must end the JOB, not leave its peer waiting (round 4's 2-rank hang): the rank's body
+    runs under `dist.rank_guard` (logs the rank, leaves non-zero at once), torchrun then stops the peer, the launcher relays the
+    failure.  CPU rehearsal: gloo, --dry-run, the failure injected into rank 1 before the all_gather rank 0 enters."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ST_BENCH_FAIL_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", "--dry-run"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    took = time.time() - t0
+    err = p.stderr.decode() + p.stdout.decode()
+    assert p.returncode != 0, err[-2000:]
+    assert "rank 1/2 failed in bench.py worker" in err and "injected failure" in err, err[-3000:]
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{") and '"metric"' in ln]     # no bench line from a broken job
+    assert took < 120, took
+
+
+GUARD_WORKER = textwrap.dedent("""
+    import os, sys, torch
+    sys.path.insert(0, %r)
+    import stitch_amd
+    from stitch_amd import dist as sd
+    with sd.rank_guard("test body"):
+        rank, world, local = sd.init(backend="gloo")
+        if rank == 1:
+            raise ValueError("rank 1 breaks before the gather")
+        sd.gather_metrics([0], [[1.0, 2.0]], 2, k=2)          # rank 0 waits here for a peer that is gone
+        print("UNREACHABLE")
+""") % ROOT
+
+
+def test_peer_of_a_dead_rank_times_out_without_a_launcher(tmp_path):
+    """No torchrun above the ranks (plain processes): the dead rank leaves non-zero with its rank in the log, and the survivor falls
+    out of the collective (peer closed / the finite `dist.timeout()` every process group here is opened with) instead of waiting forever."""
+    script = tmp_path / "guard_worker.py"
+    script.write_text(GUARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2", ST_DIST_TIMEOUT_S="20")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=200)[0].decode() for p in procs]
+    assert procs[1].returncode == 1 and "rank 1/2 failed in test body: ValueError" in outs[1], outs[1][-2000:]
+    assert procs[0].returncode != 0 and "UNREACHABLE" not in outs[0] and "rank 0/2 failed in test body" in outs[0], outs[0][-2000:]
+
+
+def test_every_process_group_gets_a_finite_timeout():
+    """grep-level guard: no init_process_group in the product tree without timeout=."""
+    import glob
+    import re
+    files = [os.path.join(ROOT, f) for f in ("bench.py", "out.py", "evaluate.py")] + glob.glob(os.path.join(ROOT, "seamless-*", "*.py"))
+    for f in files:
+        src = open(f).read()
+        for m in re.finditer(r"init_process_group\(", src):
+            call = src[m.start():src.index("\n", src.index(")", m.start()) if ")" in src[m.start():] else m.start())]
+            depth, end = 0, m.end() - 1
+            for i in range(m.end() - 1, len(src)):
+                depth += src[i] == "("
+                depth -= src[i] == ")"
+                if depth == 0:
+                    end = i
+                    break
+            assert "timeout=" in src[m.start():end], (f, src[m.start():end])

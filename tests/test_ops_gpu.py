@@ -1,6 +1,7 @@
 """Per-kernel parity on the GPU: every HIP entry point (called through the C-ABI) against the CPU
 oracle on the same seeded inputs.  Tolerances: integer / index / mask data bit-exact; fp32
 contractions 1e-4 relative (different accumulation order); resampling < 1e-3 (north_star)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -413,30 +414,40 @@ def test_range_map_occlusion_open(ops, golden_ops):
 
 
 def test_tps(ops, golden_ops):
-    """UDIS2 TPS transformer (torch_tps_transform.py:7-190) against the oracle AND the reference golden `tps_out`.
-    The contraction T @ grid is the same ascending-k fused chain torch.matmul uses for this shape (measured bit for
-    bit); what is left differs only through logf (torch: SLEEF u10, here: ocml, both <= 1 ulp) inside r^2 log r^2 and
-    through the fp64 solve's last bits before the cast to fp32, so sample indices agree except where a coordinate
-    lands within ~1e-5 px of an integer."""
+    """UDIS2 TPS transformer (torch_tps_transform.py:7-190) against the REFERENCE's own T and output (tests/golden/ops_small.npz `tps_out`,
+    tests/golden/tps_floor.npz `tps_T`; generator: oracle/ref_harness/make_tps_floor_golden.py).
+    The contraction T @ grid is the same ascending-k fused chain torch.matmul uses for this shape, the fp64 solve agrees with
+    torch.inverse to the last fp32 bit of T (cond(W) = 4e4), linspace / floor / gather are restated operation for operation: the ONE
+    thing left is the fp32 log inside r^2 log r^2.  torch-CPU's is MKL VML vsLn, a closed algorithm whose bits depend on the instruction set
+    MKL dispatches to (AVX-512: correctly rounded on 99.97 % of inputs, AVX2: 92.8 %); the kernel computes the correctly rounded log
+    (csrc/common.h st_logf_cr).  Against the AVX-512 golden 28 of 57 122 kernel entries of W differ by one ulp, which the solve turns into
+    1.8e-7 of T and 1.7e-4 px of sample coordinate -- 0.027 grey levels on this 0..255 NOISE image (gradient up to 255 / px).  The reference
+    differs from ITSELF by more between two hosts (floor_avx2_*, floor_sse4_2_*: T 1e-5, output 0.05-0.10): the bounds below are that floor,
+    not a multiple of this build's own measurement; north_star's 1e-3 is below it for this op."""
     U, src, tgt = T(golden_ops["tps_U"]), T(golden_ops["tps_source"]), T(golden_ops["tps_target"])
+    floor = np.load(os.path.join(os.path.dirname(__file__), "golden", "tps_floor.npz"))
+    gold_T = T(floor["tps_T"])
     out, Tm, idx = ops.tps_transform(dev(U), dev(src), dev(tgt), (24, 28), want_idx=True)
+    relT = (Tm.cpu() - gold_T).abs().max().item() / max(1.0, gold_T.abs().max().item())
+    check("tps_T_rel", relT, 1e-6)               # measured 1.8e-7; reference vs itself (AVX2 / SSE4.2 MKL): 1.0e-5
+    assert relT < 0.1 * min(float(floor["floor_avx2_tps_T_rel"]), float(floor["floor_sse4_2_tps_T_rel"]))
+    # informational: the oracle on THIS host (its torch.log is this host's MKL path)
     ref_out, ref_T = geom.tps_transformer(U, src, tgt, (24, 28))
-    relT = (Tm.cpu() - ref_T).abs().max().item() / max(1.0, ref_T.abs().max().item())
-    check("tps_T_rel", relT, 1e-4)               # fp64 solve of a 172x172 system whose entries were rounded to fp32 first
-    # the oracle's own sample indices from its T and grid (same _interpolate arithmetic as the homography transformer)
-    ref_idx, frac = geom.tps_indices(src, ref_T, U.shape[-2:], (24, 28), return_frac=True)
+    host_rel = (ref_T - gold_T).abs().max().item() / gold_T.abs().max().item()
+    # sample indices from the reference's T (same _interpolate arithmetic as the homography transformer)
+    ref_idx, frac = geom.tps_indices(src, gold_T, U.shape[-2:], (24, 28), return_frac=True)
     mism = (idx.cpu() != ref_idx).any(-1)
-    near = frac < 1e-4                            # a sample coordinate within 1e-4 px of an integer may floor either way (same
-    #                                               exemption style as the occlusion threshold test): logf differs in the last bit
+    near = frac < 1e-4                            # a sample coordinate within 1e-4 px of an integer may floor either way
     check("tps_idx_mismatches_off_integer", int((mism & ~near).sum()), 0, inclusive=True)
     d = (out.cpu() - T(golden_ops["tps_out"])).abs()
     same = ~mism[:, None].expand_as(d)
-    print(f"[tps] T rel {relT:.2e}; idx mismatches {int(mism.sum())} / {mism.numel()}; |out - golden| max {d.max():.3e} "
-          f"(where idx agree: {d[same].max():.3e})")
+    print(f"[tps] T rel vs reference golden {relT:.2e} (this host's oracle vs the golden: {host_rel:.2e}); idx mismatches {int(mism.sum())} / "
+          f"{mism.numel()}; |out - golden| max {d.max():.3e} (where idx agree: {d[same].max():.3e})")
     check("tps_idx_mismatches_total", int(mism.sum()), int(near.sum()), inclusive=True)
-    # same 4 taps, weights from coordinates that agree to ~1e-4 px, on a 0..255 NOISE image (|gradient| up to 255 / px)
-    check("tps_out_same_taps_max", d[same].max(), 0.1)      # measured 0.0768
-    check("tps_out_p99", np.percentile(d.numpy(), 99), 5e-2)
+    ref_floor_max = min(float(floor["floor_avx2_tps_out_max"]), float(floor["floor_sse4_2_tps_out_max"]))        # 0.0515
+    ref_floor_p99 = min(float(floor["floor_avx2_tps_out_p99"]), float(floor["floor_sse4_2_tps_out_p99"]))        # 0.0183
+    check("tps_out_same_taps_max", d[same].max(), ref_floor_max)      # measured 0.0265 (round 4, ocml logf: 0.0768)
+    check("tps_out_p99", np.percentile(d.numpy(), 99), ref_floor_p99)
 
 
 def test_blend_and_eval_finish(ops):

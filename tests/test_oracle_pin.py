@@ -438,3 +438,35 @@ def test_tps_fp32_solve_is_lapack_dependent(capsys):
     assert big["cond"] > 1e6
     assert big["mkl_vs_fp64"] > 1e-3 and big["unblocked_vs_mkl_min"] > 1e-3          # any two fp32 LUs are ~1e-2 apart here ...
     assert big["unblocked_vs_mkl_max"] < 10 * big["mkl_vs_fp64"]                     # ... no further than MKL is from the exact solution
+
+
+def test_tps_log_is_the_only_host_dependent_term_and_cr_log_is_within_the_reference_floor():
+    """tests/golden/tps_floor.npz (oracle/ref_harness/make_tps_floor_golden.py): the reference's T on the golden control points and the
+    reference's own spread between MKL code paths.  (1) With THIS host's torch.log the oracle reproduces the golden T bit for bit when the
+    host runs the generator's MKL kernel (recognised by the same share of correctly rounded results on a probe), otherwise within the
+    recorded floor.  (2) The correctly rounded log -- what the HIP kernels compute (csrc/common.h st_logf_cr) -- puts T within 1e-6 of
+    the golden, ten times inside the floor."""
+    g = np.load(os.path.join(GOLDEN, "ops_small.npz"))
+    fl = np.load(os.path.join(GOLDEN, "tps_floor.npz"))
+    src, tgt, U = T(g["tps_source"]), T(g["tps_target"]), T(g["tps_U"])
+    gold_T = T(fl["tps_T"])
+    x = (np.random.default_rng(1).random(4_000_000, dtype=np.float32) * 8).astype(np.float32)
+    here = float((torch.log(T(x)).numpy() != np.log(x.astype(np.float64)).astype(np.float32)).mean())
+    _, Tm = geom.tps_transformer(U, src, tgt, (24, 28))
+    rel = (Tm - gold_T).abs().max().item() / gold_T.abs().max().item()
+    floor_T = max(float(fl["floor_avx2_tps_T_rel"]), float(fl["floor_sse4_2_tps_T_rel"]))
+    if abs(here - float(fl["generator_log_vs_cr_frac"])) < 1e-5:
+        assert torch.equal(Tm, gold_T)
+    else:
+        assert rel <= 1.5 * floor_T, (rel, floor_T)
+    # (2) the same system with the correctly rounded fp32 log
+    B, N, _ = src.shape
+    p = torch.cat([torch.ones(B, N, 1), src], 2)
+    d2 = ((p[:, :, None, :] - p[:, None, :, :]) ** 2).sum(3)
+    cr = T(np.log((d2 + 1e-6).numpy().astype(np.float64)).astype(np.float32))
+    Wm = torch.cat([torch.cat([p, d2 * cr], 2), torch.cat([torch.zeros(B, 3, 3), p.permute(0, 2, 1)], 2)], 1).double()
+    tp = torch.cat([tgt, torch.zeros(B, 3, 2)], 1).double()
+    T_cr = torch.matmul(T(cgeom.inverse_f64(Wm.numpy())), tp).permute(0, 2, 1).float()
+    rel_cr = (T_cr - gold_T).abs().max().item() / gold_T.abs().max().item()
+    assert rel_cr < 1e-6 and rel_cr < 0.1 * min(float(fl["floor_avx2_tps_T_rel"]), float(fl["floor_sse4_2_tps_T_rel"])), rel_cr
+    assert float(fl["floor_avx2_tps_out_max"]) > 1e-3 and float(fl["floor_sse4_2_tps_out_max"]) > 1e-3      # 1e-3 is below the reference's own spread

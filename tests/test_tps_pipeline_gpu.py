@@ -122,9 +122,15 @@ def test_pipeline_vs_oracle_and_reference_golden(tp, gold, name):
           f"mask flips {mask_flips} mix-mask flips {mix_flips} blend: {(db > 0).float().mean():.2e} of bytes differ, max {int(db.max())}")
     check(f"tps_pipe_{name}_mask_flips", mask_flips, 2, inclusive=True)                      # a mask value within rounding of the 0.5 threshold
     check(f"tps_pipe_{name}_mixmask_flips", mix_flips, 2, inclusive=True)           # measured 0
-    check(f"tps_pipe_{name}_tps_p99", np.percentile(d.numpy(), 99), {"a": 2.3e-2, "b": 7e-2}.get(name, 7e-2))      # measured 7.5e-3 (a) / 2.3e-2 (b) grey levels
+    # bounds = the REFERENCE's own spread between two MKL code paths on these very inputs (tests/golden/tps_floor.npz, written by
+    # oracle/ref_harness/make_tps_floor_golden.py: the reference under MKL_ENABLE_INSTRUCTIONS=AVX2 / SSE4_2 against itself under AVX-512;
+    # its fp32 vsLn and its fp32 LU both change bits with the instruction set), not a multiple of this build's measurement
+    floor = np.load(os.path.join(os.path.dirname(__file__), "golden", "tps_floor.npz"))
+    f_p99 = max(float(floor[f"floor_avx2_pipe_{name}_tps_p99"]), float(floor[f"floor_sse4_2_pipe_{name}_tps_p99"]))                      # a 0.0140, b 0.0403
+    f_frac = max(float(floor[f"floor_avx2_pipe_{name}_blend_differs_frac"]), float(floor[f"floor_sse4_2_pipe_{name}_blend_differs_frac"]))  # a 2.9e-4, b 7.6e-4
+    check(f"tps_pipe_{name}_tps_p99", np.percentile(d.numpy(), 99), f_p99)          # measured 7.5e-3 (a) / 2.3e-2 (b) grey levels
     check(f"tps_pipe_{name}_blend_gt1_frac", (db > 1).float().mean(), 1e-4)        # measured 0: no byte is off by more than one level
-    check(f"tps_pipe_{name}_blend_differs_frac", (db > 0).float().mean(), {"a": 3e-4, "b": 8e-4}.get(name, 8e-4))    # measured 1e-4 (a) / 2.7e-4 (b) (fp64 solve vs the reference's fp32 LU)
+    check(f"tps_pipe_{name}_blend_differs_frac", (db > 0).float().mean(), f_frac)    # measured 1e-4 (a) / 2.7e-4 (b) (fp64 solve vs the reference's fp32 LU)
     gm = np.unpackbits(gold[f"pipe_{name}_mask2_bits"])[:oh * ow].reshape(oh, ow)
     assert int((got["mask2"].cpu()[0, 0].numpy() != gm).sum()) <= 4
 
