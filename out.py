@@ -222,6 +222,7 @@ def run_pairs(cfg, todo, save_root, model, composition_model=None, inpainter=Non
         def launch(j):
             k = j % depth
             arrays = decoded[j].result()
+            decoded[j] = None                  # the Future keeps both uint8 arrays alive: release it (the reference's loop holds one pair)
             if j + depth + 1 < len(todo):
                 decoded.append(dec_pool.submit(decode, todo[j + depth + 1]))
             with torch.cuda.stream(streams[k]):

@@ -47,6 +47,22 @@ class FlowHomoAdpater(nn.Module):
         self._eval_pipeline = None       # captured graphs point at the previous weights' packed copies
         return super().load_state_dict(state_dict, strict=strict)
 
+    def weights_generation(self, deep=False):
+        """Identity of the weights a captured hipGraph was recorded against.  The backbones drop their packed copies (and bump ``_gen``) on
+        ``load_state_dict`` and on every ``_apply`` (``.cuda()`` / ``.float()`` / ``.to()``), also when called on a sub-module alone
+        (``model.flow_backbone.load_state_dict(...)``): a graph recorded before that would replay kernels that read freed or stale packed
+        copies next to live parameters.  Every graph holder (``GraphedForward``, ``GraphedTestOut``, ``evaluate.EvalPipeline``) stores this
+        value at capture and re-captures on mismatch.  ``deep=True`` adds the parameters' in-place version counters (``p.data`` writes,
+        optimiser steps) and storage addresses -- 699 tensors, checked once per harness run rather than per pair."""
+        g = (getattr(self.homo_backbone, "_gen", 0), getattr(self.flow_backbone, "_gen", 0))
+        if deep:
+            v = a = 0
+            for t in self.parameters():
+                v += t._version
+                a ^= t.data_ptr()
+            g += (v, a)
+        return g
+
     # ------------------------------------------------------------------ small host-side constants
     def _mat(self, dev, key, rows):
         k = (key, str(dev))
@@ -248,6 +264,10 @@ class GraphedTestOut:
             raise NotImplementedError("inference-only drop-in: call .eval() first")
         key = (tuple(input1_tensor.shape), input1_tensor.device.index)
         ent = self._graphs.get(key)
+        gen = m.weights_generation()
+        if ent is not None and ent[5] != gen:          # weights re-packed since the capture: the graph reads dead copies
+            ent = None
+            self._graphs.clear()
         with torch.no_grad():
             if ent is None:
                 a, b = input1_tensor.float().contiguous().clone(), input2_tensor.float().contiguous().clone()
@@ -262,7 +282,7 @@ class GraphedTestOut:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph), ops.workspace_scope(ws):
                     nets = m._test_out_nets(a, b)
-                ent = self._graphs[key] = (graph, a, b, nets, ws)
+                ent = self._graphs[key] = (graph, a, b, nets, ws, m.weights_generation())
             graph, a, b, nets = ent[:4]
             a.copy_(input1_tensor)
             b.copy_(input2_tensor)
@@ -294,6 +314,9 @@ class GraphedForward:
     def __call__(self, input1_tensor, input2_tensor):
         key = (tuple(input1_tensor.shape), input1_tensor.device.index)
         ent = self._graphs.get(key)
+        if ent is not None and ent[5] != self.model.weights_generation():       # weights re-packed since the capture
+            ent = None
+            self._graphs.clear()
         if ent is None:
             a, b = input1_tensor.float().contiguous().clone(), input2_tensor.float().contiguous().clone()
             ws = ops.new_workspace(a.device)            # this graph's own split-K slabs (graphs may replay concurrently)
@@ -307,7 +330,7 @@ class GraphedForward:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph), ops.workspace_scope(ws):
                 out = self.model(a, b, type=self.type)
-            ent = self._graphs[key] = (graph, a, b, out, ws)
+            ent = self._graphs[key] = (graph, a, b, out, ws, self.model.weights_generation())
         graph, a, b, out = ent[:4]
         a.copy_(input1_tensor)
         b.copy_(input2_tensor)

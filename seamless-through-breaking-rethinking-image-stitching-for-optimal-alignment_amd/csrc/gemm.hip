@@ -1689,7 +1689,8 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
     // otherwise be many short workgroups (two resident per CU with this LDS footprint)
     const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M &&
                        d.Ho * d.Wo == d.M;
-    const int slots = 512 / batch;
+    static const int slots_env = [] { const char* e = getenv("ST_PERSIST_SLOTS"); return e ? atoi(e) : 512; }();     // experiment switch (tools/persist_probe.py)
+    const int slots = slots_env / batch;
     if (STAGES == 4 && plain && !d.a2 && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
         int G = slots / ntn;
         if (G > ntm) G = ntm;

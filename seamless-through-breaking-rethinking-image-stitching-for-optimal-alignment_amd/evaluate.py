@@ -128,6 +128,7 @@ class EvalPipeline:
     host never runs more than 2 k pairs ahead."""
 
     MAX_OUTSTANDING = 2
+    MAX_SHAPES = 4          # distinct (batch, H, W, dtype) kept captured; each costs nslots x (a forward's activations + 64 MiB workspace + pinned staging)
 
     def __init__(self, model, device, streams=3, decode_workers=None):
         self.model, self.device, self.nslots = model, device, max(1, int(streams))
@@ -137,13 +138,39 @@ class EvalPipeline:
             ncpu = os.cpu_count() or 1
         self.workers = decode_workers or max(2, min(4, ncpu // 2))     # 1.7 ms per 512x512 pair and thread: 4 threads feed ~2 000 pairs/s
         self.copy_stream = torch.cuda.Stream(device=device)
-        self._slots = {}
+        self._slots = {}                # (shape, u8) -> {slot index: _Slot}, in least-recently-used order
+        self._gen = None
 
     def _slot(self, k, shape, u8):
-        key = (k, shape, u8)
-        if key not in self._slots:
-            self._slots[key] = _Slot(self.model, self.device, shape, u8)
-        return self._slots[key]
+        """The slot (stream + graph) number k for this input shape; captured on first use.  The cache is bounded: a dataset of many image
+        sizes (or ragged batch tails) evicts the least recently used SHAPE -- its graphs, private pools and pinned buffers go with it."""
+        key = (shape, u8)
+        group = self._slots.pop(key, None)
+        if group is None:
+            group = {}
+            while len(self._slots) >= self.MAX_SHAPES:
+                old = self._slots.pop(next(iter(self._slots)))
+                for sl in old.values():
+                    sl.stream.synchronize()
+                    sl.graph = None
+                old.clear()
+        self._slots[key] = group                        # most recently used last
+        if k not in group:
+            group[k] = _Slot(self.model, self.device, shape, u8)
+        return group[k]
+
+    def n_captured(self):
+        return sum(len(g) for g in self._slots.values())
+
+    def _check_weights(self):
+        """Graphs replay against the packed weights they were captured with: drop them all when the model's weights changed identity since
+        (sub-module ``load_state_dict``, ``.to()`` / ``.float()``, in-place parameter writes) -- ``FlowHomoAdpater.weights_generation``."""
+        gen = self.model.weights_generation(deep=True) if hasattr(self.model, "weights_generation") else None
+        if gen != self._gen:
+            if self._slots:
+                torch.cuda.synchronize(self.device)
+            self._slots.clear()
+            self._gen = gen
 
     @staticmethod
     def _load(dataset, idx):
@@ -177,6 +204,7 @@ class EvalPipeline:
 
     def run(self, dataset, groups):
         """groups: list of index lists (one forward each).  Returns a CPU fp64 [sum(len(g)), 2] table in group order."""
+        self._check_weights()
         n_rows = sum(len(g) for g in groups)
         table = torch.full((max(1, n_rows), 2), float("nan"), dtype=torch.float64, device=self.device)
         ready = torch.cuda.Event()

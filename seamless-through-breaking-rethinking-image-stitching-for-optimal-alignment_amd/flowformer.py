@@ -46,11 +46,13 @@ class FlowFormer(ParamTree):
         self.cfg = cfg
         self._pk = None
         self._const = {}
+        self._gen = 0                    # bumped whenever the packed weights are dropped: captured hipGraphs compare it before replay
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
     def _invalidate(self):
         self._pk = None
         self._const = {}
+        self._gen += 1
 
     def _apply(self, fn, *a, **k):
         self._invalidate()
@@ -218,7 +220,8 @@ class FlowFormer(ParamTree):
         if proj is not None:
             att, (pw, pb), pres = proj
             dev = att.device
-            if fc1_ln is not None and FUSE_LN and FUSE_MLP and FUSE_PROJ and att.shape[1] == 128 and pw.is_contiguous():
+            if (fc1_ln is not None and FUSE_LN and FUSE_MLP and FUSE_PROJ and att.shape[1] == 128 and pw.is_contiguous()
+                    and fc2[0].is_contiguous() and fc1_ln[0].is_contiguous() and pw.data_ptr() % 16 == 0 and pb.data_ptr() % 16 == 0):
                 o = _new(att.shape[0], 128, dev) if out is None else out
                 return ops.mlp128(att, o, fc1_ln[0], fc1_ln[1], fc2[0], fc2[1], ln_eps=eps, res=extra_res, proj=(pw, pb, pres))
             x = _new(att.shape[0], att.shape[1], dev)

@@ -38,10 +38,15 @@ class UDIS2Network(ParamTree):
         super().__init__(homo_spec())
         self.only_homo = only_homo
         self._pk = None
-        self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_pk", None))
+        self._gen = 0                    # see FlowFormer._gen
+        self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
+
+    def _invalidate(self):
+        self._pk = None
+        self._gen += 1
 
     def _apply(self, fn, *a, **k):
-        self._pk = None
+        self._invalidate()
         return super()._apply(fn, *a, **k)
 
     # ------------------------------------------------------------------ weight prepack

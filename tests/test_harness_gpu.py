@@ -92,14 +92,80 @@ def test_pipelined_eval_harness_equals_the_plain_loop(tmp_path, model):
     assert torch.equal(tab_p, tab_e), (tab_p - tab_e).abs().max()
     assert str(res_p) == str(res_e)                 # (NaN entries: fewer than 663 pairs leave the mid / hard slices empty)
     pipe = model._eval_pipeline
-    n_graphs = len(pipe._slots)
-    assert n_graphs == 3
+    n_graphs = pipe.n_captured()
+    assert n_graphs == 3 and len(pipe._slots) == 1
     _, tab_again = ev.validate_with_model(model, ds, streams=3)            # replays the same graphs
-    assert torch.equal(tab_again, tab_p) and len(model._eval_pipeline._slots) == n_graphs and model._eval_pipeline is pipe
+    assert torch.equal(tab_again, tab_p) and model._eval_pipeline.n_captured() == n_graphs and model._eval_pipeline is pipe
     # batches (evaluate.py:34 uses 12): a full batch of 3 and a ragged tail of 2 are two graph shapes; rows keep dataset order
     _, tab_b = ev.validate_with_model(model, ds, batch_size=3, streams=2)
     _, tab_be = ev.validate_with_model(model, ds, batch_size=3, pipelined=False)
     assert torch.equal(tab_b, tab_be)
+
+
+def test_graphs_are_recaptured_when_the_weights_change_identity(tmp_path, model, seeded_sd):
+    """a captured graph reads the PACKED copies of the weights it was recorded with.  `model.flow_backbone.load_state_dict`
+    (a sub-module's own load: the adapter's override never runs), `.float()` / `.to()` (an `_apply`, even a no-op) and in-place parameter
+    writes all leave those copies dead or stale.  Every graph holder compares `FlowHomoAdpater.weights_generation()` before replaying and
+    re-captures on mismatch: after each change the pipelined harness, `GraphedForward` and `GraphedTestOut` must equal the eager path."""
+    from stitch_amd import evaluate as ev
+    from stitch_amd.data import structured_pair
+    _write_split(str(tmp_path), 3)
+    ds = ev.UDISDataset(str(tmp_path) + "/", phase="testing")
+    _, tab0 = ev.validate_with_model(model, ds, streams=2)
+    g, gt = model.graphed("test_eval"), model.graphed_test_out()
+    a, b = (t.cuda() for t in structured_pair(512, 512, seed=41))
+    c, d = (t.cuda() for t in structured_pair(304, 400, seed=77, shift=(3, -4)))
+    g(a, b), gt(c, d)
+    prefix = "flow_backbone."
+    other = {k[len(prefix):]: (v * 0.97 if v.dtype.is_floating_point and v.ndim >= 2 else v) for k, v in seeded_sd.items() if k.startswith(prefix)}
+    try:
+        gen0 = model.weights_generation()
+        model.flow_backbone.load_state_dict(other, strict=True)                    # not through FlowHomoAdpater.load_state_dict
+        assert model.weights_generation() != gen0
+        _, tab_p = ev.validate_with_model(model, ds, streams=2)
+        _, tab_e = ev.validate_with_model(model, ds, pipelined=False)
+        assert torch.equal(tab_p, tab_e) and not torch.equal(tab_p, tab0)
+        ref = model(a, b, type="test_eval")
+        o = g(a, b)
+        assert torch.equal(o["final_warp_output"], ref["final_warp_output"]) and torch.equal(o["flow_predictions"][0], ref["flow_predictions"][0])
+        ref_t = model(c, d, type="test_out")
+        o_t = gt(c, d)
+        assert torch.equal(o_t["blend_image"], ref_t["blend_image"]) and torch.equal(o_t["residual_flow"], ref_t["residual_flow"])
+        # a no-op _apply drops the packed copies as well
+        model.float()
+        o = g(a, b)
+        assert torch.equal(o["final_warp_output"], ref["final_warp_output"])
+        # an in-place write to one parameter (no hook fires): seen by the harness's deep check at the start of a run
+        with torch.no_grad():
+            w = next(p for n, p in model.homo_backbone.named_parameters() if p.ndim == 4)
+            w.mul_(1.01)
+        model.homo_backbone._invalidate()                                           # the packed copy is the caller's to refresh after a raw write
+        _, tab_p2 = ev.validate_with_model(model, ds, streams=2)
+        _, tab_e2 = ev.validate_with_model(model, ds, pipelined=False)
+        assert torch.equal(tab_p2, tab_e2)
+    finally:
+        model.load_state_dict(seeded_sd, strict=True)
+    _, tab_back = ev.validate_with_model(model, ds, streams=2)
+    assert torch.equal(tab_back, tab0)
+
+
+def test_eval_pipeline_keeps_a_bounded_number_of_shapes(tmp_path, model):
+    """the graph cache is an LRU over input shapes (`EvalPipeline.MAX_SHAPES`), not an ever-growing dict.  The nets run
+    at 512x512 only (`test_eval`), so the shapes here are batch sizes: batches of 1..5 with their ragged tails are 5 distinct shapes."""
+    from stitch_amd import evaluate as ev
+    _write_split(str(tmp_path), 5)
+    ds = ev.UDISDataset(str(tmp_path) + "/", phase="testing")
+    model._eval_pipeline = None
+    tabs = {}
+    for bs in (1, 2, 3, 4, 5):
+        _, tabs[bs] = ev.validate_with_model(model, ds, batch_size=bs, streams=2)
+        assert len(model._eval_pipeline._slots) <= ev.EvalPipeline.MAX_SHAPES
+    pipe = model._eval_pipeline
+    # batch sizes 2 and 4 leave a tail of one pair (shape 1 stays recently used); the least recently used shape, 3, went
+    assert len(pipe._slots) == ev.EvalPipeline.MAX_SHAPES and {k[0][0] for k in pipe._slots} == {1, 2, 4, 5}
+    _, again = ev.validate_with_model(model, ds, batch_size=3, streams=2)           # evicted shape, captured again: same bits
+    assert torch.equal(again, tabs[3]) and model._eval_pipeline is pipe and len(pipe._slots) == ev.EvalPipeline.MAX_SHAPES
+    model._eval_pipeline = None
 
 
 def test_pipelined_eval_mixed_shapes_and_generic_dataset(tmp_path, model):
