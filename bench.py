@@ -58,6 +58,9 @@ def parse_args(argv=None):
                          "--harness-pairs synthetic 512x512 JPEG pairs written to a temp dir (JPEG decode + H2D + forward + metric + final "
                          "copy inside the clock) -> harness_pairs_per_s beside value")
     ap.add_argument("--harness-pairs", type=int, default=240)
+    ap.add_argument("--harness-batch", type=int, default=4,
+                    help="the harness is timed twice: one pair per forward (like `value`) and batches of this size (the reference's loader "
+                         "batches 12, evaluate.py:34) -> harness_batched_pairs_per_s; 0 or 1 = skip the batched pass")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank computes on cuda:0 (use with --backend gloo; RCCL needs one GPU per rank)")
     return ap.parse_args(argv)
 
@@ -67,7 +70,7 @@ def launcher_command(args, port):
     """The torchrun command line the parent starts for ``--gpus N`` (kept separate so the CPU test can check it)."""
     fwd = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
            "--streams", str(args.streams), "--batch", str(args.batch), "--backend", args.backend, "--harness", args.harness,
-           "--harness-pairs", str(args.harness_pairs)]
+           "--harness-pairs", str(args.harness_pairs), "--harness-batch", str(args.harness_batch)]
     for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-corr-roofline", args.no_corr_roofline),
                      ("--eager", args.eager), ("--dry-run", args.dry_run), ("--share-gpu", args.share_gpu)):
         if on:
@@ -277,8 +280,32 @@ def harness_eval(model, args, rank, world, dist, log):
         same = bool(torch.equal(plain, table[:len(sub)]))
         if not same:
             log(f"plain loop vs pipelined harness differ:\n{plain}\n{table[:len(sub)]}")
+        batched = None
+        hb = int(getattr(args, "harness_batch", 0))
+        if hb > 1:
+            # the same split in batches of hb pairs per forward (evaluate.py:34 batches 12): every GEMM has hb x the rows
+            bstreams = max(2, min(args.streams, 3))
+            warm.image_list = ds.image_list[:hb * 2 * bstreams * world]
+            sev.validate_with_model(model, warm, batch_size=hb, streams=bstreams, device=dev)
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
+            t2 = time.perf_counter()
+            ds_b = sev.UDISDataset(root + "/", phase="testing")
+            _, table_b = sev.validate_with_model(model, ds_b, batch_size=hb, streams=bstreams, device=dev)
+            torch.cuda.synchronize()
+            tb = torch.tensor([time.perf_counter() - t2], device="cuda")
+            if dist:
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            sub_b = sev.UDISDataset(root + "/", phase="testing")
+            sub_b.image_list = sub_b.image_list[:2 * hb * world]
+            _, plain_b = sev.validate_with_model(model, sub_b, batch_size=hb, pipelined=False, device=dev)
+            d = (table_b - table).abs()
+            batched = {"batch": hb, "streams": bstreams, "pairs_per_s": n / tb.item(), "seconds": tb.item(),
+                       "plain_loop_table_equal": bool(torch.equal(plain_b, table_b[:len(sub_b)])),
+                       "vs_batch1_psnr_max_abs_dB": float(d[:, 0].max()), "vs_batch1_ssim_max_abs": float(d[:, 1].max())}
         return {"pairs": n, "seconds": tmax.item(), "pairs_per_s": n / tmax.item(), "avg_psnr": result["avg_psnr"], "avg_ssim": result["avg_ssim"],
-                "plain_loop_pairs_per_s": len(sub) / dt_plain, "plain_loop_table_equal": same,
+                "plain_loop_pairs_per_s": len(sub) / dt_plain, "plain_loop_table_equal": same, "batched": batched,
                 "what": f"stitch_amd.evaluate.validate_with_model on {n} synthetic 512x512 JPEG pairs on disk (quality 95): PIL decode in "
                         f"{model._eval_pipeline.workers} worker threads, pinned H2D, uint8->float + forward(test_eval) + masked PSNR/SSIM in one "
                         f"hipGraph per pair, {args.streams} pairs in flight, one device->host copy of the table; clock = dataset listing .. "
@@ -472,7 +499,9 @@ def worker(args):
                        "pairs_in_flight": nstreams * nb,
                        "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective, one all_gather of per-pair metrics"
                                       + (" [REHEARSAL: all ranks share cuda:0]" if args.share_gpu else "")},
-            "harness_pairs_per_s": None if harness is None else harness["pairs_per_s"], "harness": harness,
+            "harness_pairs_per_s": None if harness is None else harness["pairs_per_s"],
+            "harness_batched_pairs_per_s": None if harness is None or not harness.get("batched") else harness["batched"]["pairs_per_s"],
+            "harness": harness,
             "value_1_in_flight": None if dt1 is None else world * max(10, args.steps // 2) * nb / dt1,
             "per_rank_pairs_per_s": {"min": min(per_rank_pairs_s), "max": max(per_rank_pairs_s), "ranks": len(per_rank_pairs_s)},
             "roofline": {"bound": "mfma", "kernel": "fp32 MFMA GEMM family: conv_gemm_dma_kernel + rowstream_gemm_kernel + rowmlp128_kernel + rowchain128_kernel + conv_gemm_kernel + skinny / narrow variants + split-K reducers (every st_conv_gemm / st_mlp128 / st_linear_chain128 launch of one step)",

@@ -599,17 +599,23 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
     // 8 rows per piece, lane l -> row l/8 of the piece, 16-B slot l%8 holding k-chunk (l%8) ^ ((row>>1)&7)
     int a_base[PA], a_iy0[PA], a_ix0[PA];
     unsigned voffA[PA], voffB[PB];
+    auto set_mtile = [&](int mbase) {               // per-lane decomposition (image, oy, ox) of the A rows of the M tile starting at mbase
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int r = 8 * (wave * PA + i) + (lane >> 3);
-        const int chunk4 = (((lane & 7) ^ ((r >> 1) & 7)) << 2);
-        const int m = min(m0 + r, d.M - 1);                                 // rows past M: any valid row (never stored)
-        const int hw = d.Ho * d.Wo;
-        const int b = m / hw, rr = m - b * hw;
-        const int oy = rr / d.Wo, ox = rr - oy * d.Wo;
-        a_iy0[i] = oy * d.sh - d.ph; a_ix0[i] = ox * d.sw - d.pw;
-        a_base[i] = ((b * d.H + a_iy0[i]) * d.W + a_ix0[i]) * d.ldx + chunk4;
-    }
+        for (int i = 0; i < PA; ++i) {
+            const int r = 8 * (wave * PA + i) + (lane >> 3);
+            const int chunk4 = (((lane & 7) ^ ((r >> 1) & 7)) << 2);
+            const int m = min(mbase + r, d.M - 1);                              // rows past M: any valid row (never stored)
+            const int hw = d.Ho * d.Wo;
+            const int b = m / hw, rr = m - b * hw;
+            const int oy = rr / d.Wo, ox = rr - oy * d.Wo;
+            a_iy0[i] = oy * d.sh - d.ph; a_ix0[i] = ox * d.sw - d.pw;
+            a_base[i] = ((b * d.H + a_iy0[i]) * d.W + a_ix0[i]) * d.ldx + chunk4;
+        }
+    };
+    set_mtile(m0);
+    // PERSIST walks plain matrices (rows are contiguous: set_rows) or convolutions (taps: set_mtile + set_tap at every M-tile change)
+    const bool pconv = PERSIST && !(d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M &&
+                                    d.Ho * d.Wo == d.M);
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int r = 8 * (wave * PB + i) + (lane >> 3);                    // row inside the B part; BM % 16 == 0
@@ -646,7 +652,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
             voffA[i] = (unsigned)(min(i_m0 + r, d.M - 1) * d.ldx + (((lane & 7) ^ ((r >> 1) & 7)) << 2)) * 4u;
         }
     };
-    if (PERSIST) set_rows(); else set_tap();
+    if (PERSIST && !pconv) set_rows(); else set_tap();
     auto issue_a = [&](int stage, int i) {
         lds_dma16(i_c0 < a2c ? rsrcA2 : rsrcA, lds0 + (unsigned)(stage * STAGE_FLOATS + (wave * PA + i) * 256) * 4u, voffA[i], soffA);
     };
@@ -656,7 +662,17 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
     auto advance = [&]() {                          // scalar, except the address refresh at a tap / M-tile change
         soffB += 128u; soffA += 128u;
         if (PERSIST) {
-            if (++i_kt == nkt) { i_kt = 0; soffA = 0; soffB = 0; i_m0 += G * BM; set_rows(); }
+            if (++i_kt == nkt) {
+                i_kt = 0; soffA = 0; soffB = 0; i_m0 += G * BM;
+                if (pconv) { i_c0 = 0; i_ky = 0; i_kx = 0; set_mtile(i_m0); set_tap(); } else set_rows();
+            } else if (pconv) {
+                i_c0 += 32;
+                if (i_c0 >= d.Cin) {
+                    i_c0 = 0; soffA = 0;
+                    if (++i_kx == d.kw) { i_kx = 0; ++i_ky; }
+                    set_tap();
+                }
+            }
         } else {
             i_c0 += 32;
             if (i_c0 >= d.Cin) {
@@ -1689,9 +1705,18 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
     // otherwise be many short workgroups (two resident per CU with this LDS footprint)
     const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M &&
                        d.Ho * d.Wo == d.M;
-    static const int slots_env = [] { const char* e = getenv("ST_PERSIST_SLOTS"); return e ? atoi(e) : 512; }();     // experiment switch (tools/persist_probe.py)
+    // Round-5 experiment, measured and NOT adopted (both switches default to the round-4 behaviour): ST_PERSIST_SLOTS=256 gives a launch ONE
+    // workgroup slot per CU (a CU holds two of this LDS footprint; a workgroup then walks >= 2 M tiles with one continuous DMA ring) so that the
+    // second slot is left to the kernel of another stream, and ST_PERSIST_CONV=1 lets convolutions walk that way too (the kernel re-derives its
+    // per-lane tap addresses at every M-tile change).  On uniform GEMMs the idea pays (tools/persist_probe.py, 5 decoder shapes, one hipGraph
+    // per stream: 3 streams 120.9 -> 127.8 TFLOP/s, 2 streams 119.2 -> 124.1, 1 stream 104.2 -> 102.4); in the product it does not (bench.py,
+    // 3 pairs in flight, same box, A/B/A: slots 512 conv 0: 82.66 / 82.58 pairs/s; 256 / 1: 81.09 / 80.67; 256 / 0: 82.60; 512 / 1: 82.22;
+    // one pair in flight 72.4 -> 69.0): between the GEMMs of a forward run ~150 short kernels of other kinds, and a GEMM that holds one slot
+    // runs at one wave per SIMD whenever the neighbouring stream is not in a GEMM itself.
+    static const int slots_env = [] { const char* e = getenv("ST_PERSIST_SLOTS"); return e ? atoi(e) : 512; }();
+    static const int conv_persist = [] { const char* e = getenv("ST_PERSIST_CONV"); return e ? atoi(e) : 0; }();
     const int slots = slots_env / batch;
-    if (STAGES == 4 && plain && !d.a2 && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
+    if (STAGES == 4 && (plain || (conv_persist && batch == 1)) && !d.a2 && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
         int G = slots / ntn;
         if (G > ntm) G = ntm;
         auto k = d.c_t ? conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true, true> : conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true>;

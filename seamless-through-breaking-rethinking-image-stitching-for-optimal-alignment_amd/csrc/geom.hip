@@ -257,6 +257,23 @@ extern "C" int st_dlt4(const float* src4x2, const float* motion, float* H, int32
 // Canvas bounds: min/max of the rigid (gw+1)x(gh+1) mesh of [0,width]x[0,height] mapped through
 // H^-1 with perspective divide (core/warp_utils.py:10-34, flowHomoAdpater.py:254-266).
 // out[4] = (min x, max x, min y, max y) over all batches.
+// min / max are order independent (exact), so the mesh is spread over many workgroups and the per-workgroup extremes meet in out[4]
+// through integer atomics on the float bit patterns (non-negative floats order like ints, negative ones like reversed unsigned ints);
+// a one-wave kernel sets out to (+inf, -inf, +inf, -inf) first.  One workgroup took 200 us for the reference's 513 x 513 mesh -- on the
+// critical path of test_out, right before the host reads the canvas size.
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+    v = v + 0.0f;                                   // -0.0 -> +0.0: its bit pattern is INT_MIN, which the signed compare would rank below every negative float
+    if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+    v = v + 0.0f;
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__global__ void mesh_bounds_init_kernel(float* __restrict__ out) {
+    if (threadIdx.x < 4) out[threadIdx.x] = (threadIdx.x & 1) ? -INFINITY : INFINITY;
+}
 __global__ __launch_bounds__(256) void mesh_bounds_kernel(const float* __restrict__ Hm, float* __restrict__ out, int B,
                                                           float width, float height, int gw, int gh) {
     __shared__ float red[4][4];
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(256) void mesh_bounds_kernel(const float* __restric
     for (int b = 0; b < B; ++b) {
         float hi[9];
         mat3_inv(Hm + 9 * b, hi);
-        for (int p = threadIdx.x; p < npt; p += 256) {
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < npt; p += gridDim.x * 256) {
             const float x = lin_at(0.0f, width, gw + 1, p % (gw + 1)), y = lin_at(0.0f, height, gh + 1, p / (gw + 1));
             float tx = hi[0] * x; tx = __fmaf_rn(hi[1], y, tx); tx = tx + hi[2];
             float ty = hi[3] * x; ty = __fmaf_rn(hi[4], y, ty); ty = ty + hi[5];
@@ -282,17 +299,22 @@ __global__ __launch_bounds__(256) void mesh_bounds_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0) { red[wv][0] = mnx; red[wv][1] = mxx; red[wv][2] = mny; red[wv][3] = mxy; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
-        out[1] = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
-        out[2] = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
-        out[3] = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
+        atomic_min_f32(out + 0, fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0])));
+        atomic_max_f32(out + 1, fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1])));
+        atomic_min_f32(out + 2, fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2])));
+        atomic_max_f32(out + 3, fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])));
     }
 }
 
 extern "C" int st_mesh_bounds(const float* H, float* out4, int32_t B, float width, float height, int32_t gw, int32_t gh,
                               void* stream) {
-    if (!H || !out4 || B <= 0) return ST_EINVAL;
-    hipLaunchKernelGGL(mesh_bounds_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, H, out4, B, width, height, gw, gh);
+    if (!H || !out4 || B <= 0 || gw < 0 || gh < 0) return ST_EINVAL;
+    const long npt = (long)(gw + 1) * (gh + 1);
+    int nb = (int)((npt + 1023) / 1024);                       // ~4 points per thread
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(mesh_bounds_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out4);
+    hipLaunchKernelGGL(mesh_bounds_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, H, out4, B, width, height, gw, gh);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

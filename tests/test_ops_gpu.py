@@ -368,6 +368,21 @@ def test_mesh_bounds(ops, golden_ops):
     out = torch.empty(4, device="cuda")
     ops.mesh_bounds(dev(T(golden_ops["mesh_H"])), out, 400, 300)
     assert (out.cpu() - T(golden_ops["mesh_minmax"])).abs().max() < 1e-3
+    # the multi-workgroup reduction (integer atomics on float bit patterns): extremes of either sign, batches, small meshes, and a
+    # second call into the same buffer (the init kernel, not the previous result, seeds the atomics); min / max are exact, so the
+    # int()-truncated canvas bounds the adapter derives (flowHomoAdpater.py:259-268) must equal the oracle's
+    gen = g(77)
+    for trial in range(6):
+        B = 1 + trial % 3
+        Hm = torch.eye(3)[None].repeat(B, 1, 1) + torch.randn(B, 3, 3, generator=gen) * torch.tensor([[0.05, 0.05, 60.0], [0.05, 0.05, 60.0], [1e-4, 1e-4, 0.0]])
+        w, h, gw, gh = (512, 512, 511, 511) if trial < 3 else (37 + 10 * trial, 29, 12, 7)
+        mesh = geom.h2mesh(Hm, geom.rigid_mesh(B, h, w, gh, gw))
+        want = torch.stack([mesh[..., 0].min(), mesh[..., 0].max(), mesh[..., 1].min(), mesh[..., 1].max()])
+        for rep in range(2):
+            ops.mesh_bounds(dev(Hm), out, w, h, gw, gh)
+            got = out.cpu()
+            assert (got - want).abs().max() <= 1e-3 * max(1.0, want.abs().max().item()), (trial, got, want)
+            assert torch.equal(got.int(), want.int()) or (got - want).abs().max() < 1e-4, (trial, got, want)
 
 
 def test_flow_warp_resize(ops, golden_ops):
