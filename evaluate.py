@@ -39,7 +39,10 @@ def main(argv=None):
     p.add_argument("--ckpt_path", type=str, default="./checkpoints/final_ckpt", help="ckpt path")
     p.add_argument("--model_config_name", type=str, default="last_config", help="model config")
     p.add_argument("--data_dir", type=str, default="./data/UDIS/UDIS-D/", help="data dir")
-    p.add_argument("--batch_size", type=int, default=1, help="pairs per forward (the reference's loader uses 12)")
+    p.add_argument("--batch_size", type=int, default=4,
+                   help="pairs per forward (the reference's loader batches 12, evaluate.py:34; measured on one MI355X: 82.2 pairs/s at 1, 84.2 at 2, "
+                        "84.7 at 4, 82.7 at 8 -- profiles/r5_batch_sweep.txt; per-pair results move by the batched-vs-unbatched reorder noise the "
+                        "reference shows itself, tests/golden/e2e_r5_512.npz b2_vs_b1_*)")
     args = p.parse_args(argv)
     rank, world, local = sdist.init()
     torch.cuda.set_device(local)
