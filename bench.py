@@ -214,7 +214,7 @@ def cpu_baseline_and_parity(model, ops):
                   "note": "numerical parity of the two implementations, NOT a quality figure: with the seeded random weights (no checkpoint offline) "
                           "the stitched images are ~12.4 dB from image 1 for both paths; the seeded flow network amplifies a ~1e-5 px difference of the "
                           "homography corner offsets ~1e4x, and the CPU oracle run from the HIP path's own offsets moves by the same flow / flip "
-                          "amounts (profiles/r4_parity.json: oracle_sensitivity); the enforceable criterion is the stage-held-fixed tests "
+                          "amounts (profiles/r5_parity.json: oracle_sensitivity); the enforceable criterion is the stage-held-fixed tests "
                           "(tests/test_parity_gpu.py).  Metric kernel = evaluate.py:44-65 restated from skimage 0.19's published algorithm "
                           "(skimage itself absent: parity vs skimage unpinned)"}
     finally:
@@ -471,7 +471,7 @@ def worker(args):
         flops, gemm_ms, launches, abytes = inst["flops"], inst["ms"], inst["launches"], inst["alg_bytes"]
         tf = flops / gemm_ms / 1e9
         traffic, tsrc = None, None             # HBM bytes per step of the GEMM family from the committed PMC passes
-        for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and not big and nb == 1:
                 t = json.load(open(tpath))
@@ -479,9 +479,9 @@ def worker(args):
                 tsrc = dict(provenance(tpath), how="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied "
                                                    "(tools/run_pmc_shapes.sh)", launches_per_step_in_file=t.get("launches_per_step"))
                 break
-        # per-kernel time of the same command from the committed rocprofv3 pass (tools/final_prof.sh -> profiles/r4_kernel_summary.json)
+        # per-kernel time of the same command from the committed rocprofv3 pass (tools/final_prof.sh -> profiles/r5_kernel_summary.json)
         prof, psrc = None, None
-        for name in ("r4_kernel_summary.json", "r3_kernel_summary.json"):
+        for name in ("r5_kernel_summary.json", "r4_kernel_summary.json", "r3_kernel_summary.json"):
             ppath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(ppath) and not big and nb == 1:
                 prof = json.load(open(ppath))

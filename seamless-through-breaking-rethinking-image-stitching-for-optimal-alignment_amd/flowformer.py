@@ -34,6 +34,19 @@ PAIR_CONVS = os.environ.get("ST_PAIR_CONVS", "1") != "0"       # convc2 + convf2
 FUSE_MLP = os.environ.get("ST_FUSE_MLP", "1") != "0"            # the C = 128 Twins MLPs (LN -> fc1 + GELU -> fc2 + residual) as one st_mlp128 launch
 FUSE_PROJ = os.environ.get("ST_FUSE_PROJ", "1") != "0"          # ... with the Block's attention output projection + residual in front, same launch
 FUSE_CHAIN = os.environ.get("ST_FUSE_CHAIN", "1") != "0"        # the latent layers' 128-wide tails as one st_linear_chain128 launch
+# ST_FORK=1: the context branch of a pass (cnet Twins, then everything of the decoder that only needs the context: proj_net / proj_inp, the
+# SepConvGRU tables, the GMA attention matrix) on a second HIP stream beside the feature branch (fnet Twins, correlation volume, PatchEmbed,
+# latent layers); joined by an event before the first vertical layer (context) and by a stream join before the refinement loop.  Captured
+# into the forward's hipGraph as a parallel branch.  Same kernels, same operands: bit-identical.  Measured in round 5 (section 5 of DESIGN.md).
+FORK = os.environ.get("ST_FORK", "0") == "1"
+_SIDE = {}
+
+
+def _side_stream(cur):
+    key = (cur.device_index, cur.cuda_stream)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=cur.device)
+    return _SIDE[key]
 
 
 def _new(rows, cols, dev, zero=False):
@@ -461,7 +474,7 @@ class FlowFormer(ParamTree):
                                 att[sl], (C, nl * C), nl, 8, N, Nk, 16, 16 ** -0.5)
         return self._mlp(None, V["gn2"], V["gfc1"], V["gfc2"], 1e-5, fc1_ln=V["gfc1_ln"], extra_res=extra_res, proj=(att, V["gproj"], x2))
 
-    def _cost_encoder(self, cost_maps, ctx, B, H1, W1):
+    def _cost_encoder(self, cost_maps, ctx, B, H1, W1, ctx_ready=None):
         """CostPerceiverEncoder.forward (encoder.py:258-287) -> cost memory rows [B*N*8, 128]."""
         pk = self._pk
         M = B * H1 * W1
@@ -471,6 +484,8 @@ class FlowFormer(ParamTree):
         nl = pk["latents"].shape[0]
         for i in range(HP["encoder_depth"]):
             x = self._latent_layer(pk["self"][i], x, M, False)
+            if i == 0 and ctx_ready is not None:
+                torch.cuda.current_stream().wait_event(ctx_ready)            # ST_FORK: the context comes from the side stream
             # cost_encoder_res (encoder.py:281-282) adds the short-cut to the output of the last layer: a second residual operand
             # in that layer's final GEMM epilogue (no add pass, one k/v projection in the decoder)
             x = self._vertical(pk["vert"][i], x, ctx, B, H1, W1, nl, extra_res=short if i == HP["encoder_depth"] - 1 else None)
@@ -528,22 +543,33 @@ class FlowFormer(ParamTree):
         ops.conv_gemm(S["fh"], D["m2"][0], mask, bias=D["m2"][1], alpha=0.25)
         return mask
 
-    def _decoder(self, mem, mem_short, ctx, cost_maps, B, H1, W1, iters, trace=None):
+    def _decoder_prologue(self, ctx, B, H1, W1):
+        """what the decoder derives from the context alone, once per pass: net / inp (decoder.py:283-287), the SepConvGRU tables, the GMA
+        attention matrix (gma.py:54-76)."""
+        D = self._pk["dec"]
+        dev = ctx.device
+        N = H1 * W1
+        R = B * N
+        S = self._update_state(R, B, N, dev)
+        inp = _new(R, 128, dev)
+        ops.conv_gemm(ctx, D["proj_net"][0], S["hxA"][:, :128], bias=D["proj_net"][1], act="tanh")
+        ops.conv_gemm(ctx, D["proj_inp"][0], inp, bias=D["proj_inp"][1], act="relu")
+        gru_tab = self._gru_tables(inp, B, H1, W1)
+        qk = _new(R, 256, dev)
+        attn = torch.empty((B, N, N), device=dev)
+        ops.gma_attention(inp, D["qk"], qk, attn, B, N)
+        return dict(S=S, inp=inp, gru_tab=gru_tab, attn=attn, qk=qk)
+
+    def _decoder(self, mem, mem_short, ctx, cost_maps, B, H1, W1, iters, trace=None, pre=None):
         """MemoryDecoder.forward eval branch (decoder.py:262-344)."""
         D = self._pk["dec"]
         dev = ctx.device
         N = H1 * W1
         R = B * N
         nl = self._pk["latents"].shape[0]
-        S = self._update_state(R, B, N, dev)
-        inp = _new(R, 128, dev)
-        ops.conv_gemm(ctx, D["proj_net"][0], S["hxA"][:, :128], bias=D["proj_net"][1], act="tanh")
-        ops.conv_gemm(ctx, D["proj_inp"][0], inp, bias=D["proj_inp"][1], act="relu")
-        gru_tab = self._gru_tables(inp, B, H1, W1)
-        # GMA attention, once (gma.py:54-76)
-        qk = _new(R, 256, dev)
-        attn = torch.empty((B, N, N), device=dev)
-        ops.gma_attention(inp, D["qk"], qk, attn, B, N)
+        if pre is None:
+            pre = self._decoder_prologue(ctx, B, H1, W1)
+        S, gru_tab, attn = pre["S"], pre["gru_tab"], pre["attn"]
         # k, v of the cost-memory cross attention, once (decoder.py:68-70); memory = x + short_cut (linear -> two GEMMs)
         ca = D["ca"]
         kv = _new(R * nl, 128, dev)
@@ -613,15 +639,29 @@ class FlowFormer(ParamTree):
         x = _new(2 * B * H * W, 4, dev)
         ops.prep_image(image_a.contiguous(), x[:B * H * W], 4, 2.0, 255.0, 1.0)
         ops.prep_image(image_b.contiguous(), x[B * H * W:], 4, 2.0, 255.0, 1.0)
-        ctx, H1, W1 = self._twins(pk["cnet"], x, 2 * B, H, W)          # context of a (pass a->b) then of b (pass b->a)
+        pre = ctx_ready = side = None
+        if FORK:
+            cur = torch.cuda.current_stream()
+            side = _side_stream(cur)
+            side_ws = ops.side_workspace(dev)                                # split-K slabs of the side branch (looked up on THIS stream)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), ops.workspace_scope(side_ws):
+                ctx, H1, W1 = self._twins(pk["cnet"], x, 2 * B, H, W)
+                ctx_ready = torch.cuda.Event()
+                ctx_ready.record(side)
+                pre = self._decoder_prologue(ctx, 2 * B, H1, W1)
+        else:
+            ctx, H1, W1 = self._twins(pk["cnet"], x, 2 * B, H, W)          # context of a (pass a->b) then of b (pass b->a)
         feats, _, _ = self._twins(pk["fnet"], x, 2 * B, H, W)
         N = H1 * W1
         feats = feats.view(2, B, N, 256)
         cost_maps = torch.empty((2 * B * N, N), device=dev)
         # the reverse direction's volume is the transpose of the forward one: one product, two stores
         ops.corr_volume_both(feats[0], feats[1], cost_maps[:B * N].view(B, N, N), cost_maps[B * N:].view(B, N, N))
-        mem, short = self._cost_encoder(cost_maps, ctx, 2 * B, H1, W1)
-        flow_up, coords1 = self._decoder(mem, short, ctx, cost_maps, 2 * B, H1, W1, iters)
+        mem, short = self._cost_encoder(cost_maps, ctx, 2 * B, H1, W1, ctx_ready=ctx_ready)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        flow_up, coords1 = self._decoder(mem, short, ctx, cost_maps, 2 * B, H1, W1, iters, pre=pre)
         return flow_up, coords1, (2 * B, H1, W1)
 
     def forward(self, image1, image2, mask=None, output=None, flow_init=None):

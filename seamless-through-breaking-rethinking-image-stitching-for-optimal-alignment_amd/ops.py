@@ -61,6 +61,19 @@ def new_workspace(dev):
     return torch.empty((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
 
 
+_WS_SIDE = {}
+
+
+def side_workspace(dev):
+    """the companion of the CURRENT workspace for a forked branch of the same forward (flowformer.FORK): two branches that run
+    concurrently must not share split-K slabs.  Call it before switching to the side stream."""
+    base = _workspace(dev)
+    k = (dev.type, dev.index, base.data_ptr())
+    if k not in _WS_SIDE:
+        _WS_SIDE[k] = new_workspace(dev)
+    return _WS_SIDE[k]
+
+
 class workspace_scope:
     """``with ops.workspace_scope(ws):`` -- every split-K GEMM launched inside uses ``ws``."""
 

@@ -2,7 +2,7 @@
 # GEMM per-shape table with PMC traffic (run on the GPU box from the repo root): timing pass, two rocprofv3 --pmc passes
 # (one counter each, --kernel-trace only), join.  Outputs under gpurun_out/; copy ${TAG}_gemm_shapes.csv / r3_traffic.json to profiles/.
 set -e
-TAG=${1:-r4}
+TAG=${1:-r5}
 export TMPDIR=/tmp
 O=gpurun_out/shapes
 mkdir -p $O
