@@ -135,3 +135,16 @@ def test_fold_layernorm_is_exact_algebra():
     assert (got - ref).abs().max() < 5e-6                    # (the folded weights are rounded to fp32 once)
     wf2, bf2 = stitch_amd.ops.fold_layernorm(gam, bet, w)    # no bias: b' = W @ beta
     assert torch.equal(wf2, wf) and (bf2.double() - (w.double() @ bet.double())).abs().max() < 1e-6
+
+
+def test_no_memset_call_in_capturable_code():
+    """Round 4: a `hipMemsetAsync` captured into a hipGraph did not clear the range map's accumulator on replays (csrc/geom.hip; reproducer:
+    tools/probes/graph_memset_probe.py).  Every entry point of the library may be captured, so no source of it may CALL hipMemset* /
+    hipMemcpy* (accumulators are zeroed by kernels); comments may mention them."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in glob.glob(os.path.join(root, "seamless-*", "csrc", "*.hip")) + glob.glob(os.path.join(root, "seamless-*", "csrc", "*.h")):
+        src = re.sub(r"//[^\n]*", "", open(f).read())
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        assert not re.search(r"\bhipMem(set|cpy)\w*\s*\(", src), f
