@@ -218,6 +218,12 @@ int st_ccl_softargmax(const float* G, float* out, int32_t ldo, int32_t B, int32_
  * maps [M,H,W], w [36,16] (tap-major), out [M*Ho*Wo,16]; reads beyond H/W are zero (right/bottom pad). */
 int st_patch_conv1(const float* maps, const float* w36x16, const float* bias, float* out, int32_t M, int32_t H,
                    int32_t W, int32_t Ho, int32_t Wo, void* stream);
+/* PatchEmbed.proj[0..3] per cost map in ONE launch (encoder.py:36-39,68-72: Conv2d(1,16,6,2,2) + ReLU -> Conv2d(16,32,6,2,2) + ReLU):
+ * cost_maps [M, 64*64] -> s2 rows [M*16*16, 32] (channels last), the first feature map never leaving the CU; bit-identical to
+ * st_patch_conv1 followed by the (6x3 pixel-pair) st_conv_gemm of st_patch_embed.  H = W = 64 only (ST_EINVAL otherwise: callers take
+ * the unfused launches).                                                                              */
+int st_patch_conv12(const float* cost_maps, const float* c0_w36x16, const float* c0_b, const float* c2_w32x576,
+                    const float* c2_b, float* s2, int32_t M, int32_t H, int32_t W, void* stream);
 int st_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t rows, int32_t cols, void* stream);
 /* NCHW image -> channels-last rows with v = mul*(x/div) - sub (flowHomoAdpater.py:55-56,
  * transformer.py:53-54); channels C..ldo-1 are zero.                                               */

@@ -12,7 +12,7 @@ OUT = os.path.join(HERE, "libstitch_gfx950.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # geom.hip pins every fp32 rounding (bit-exact sample indices): no fma contraction there
 SOURCES = {"gemm.hip": [], "nn.hip": [], "flowops.hip": [], "geom.hip": ["-ffp-contract=off"],
-           "metrics.hip": ["-ffp-contract=off"], "operators.hip": [], "composition.hip": ["-ffp-contract=off"], "tps_pipeline.hip": ["-ffp-contract=off"]}
+           "metrics.hip": ["-ffp-contract=off"], "operators.hip": [], "composition.hip": ["-ffp-contract=off"], "tps_pipeline.hip": ["-ffp-contract=off"], "patchembed.hip": []}
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 COMMON += [f for f in os.environ.get("ST_EXP_FLAGS", "").split() if f]      # experiment switches (e.g. -DST_EXP_PRIO), never set for the shipped build
 if os.environ.get("ST_EXACT_TRANSCENDENTALS", "0") == "1":       # diagnostic build (csrc/common.h): not the shipped arithmetic

@@ -88,12 +88,18 @@ int st_patch_embed(const float* cost_maps, const float* const* weights, int32_t 
         return ST_EINVAL;
     const int Hp = (H + 7) / 8 * 8, Wp = (W + 7) / 8 * 8;      // zero pad to the patch size (encoder.py:63-66)
     const int H1 = Hp / 2, W1 = Wp / 2, H2 = Hp / 4, W2 = Wp / 4, H3 = Hp / 8, W3 = Wp / 8, P = H3 * W3;
-    ST_TRY(st_patch_conv1(cost_maps, weights[0], weights[1], s1, M, H, W, H1, W1, stream));
-    // 16-channel input, even width / stride / padding: pixel pairs (2x', 2x'+1) are 32 contiguous channels, so the
-    // 6x6 stride-2 pad-2 conv is read as a 6x3 conv, stride (2,1), pad (2,1) over [M, H1, W1/2, 32] with the SAME
-    // weight memory ((ky,kx,c) order) -- which makes every K step one whole 128-byte line for the LDS-DMA kernel.
-    ST_TRY(Gemm(s1, 32, weights[2], 576, s2, 32, 0, 32, 32).conv(M, H1, W1 / 2, 6, 3, 2, 1, 2, 1, H2, W2)
-               .bias(weights[3]).act(ST_ACT_RELU).work(workspace, workspace_floats).run(stream));
+    // the first two convs of a 64x64 map in one launch, s1 kept on the CU (csrc/patchembed.hip; bit-identical).  ST_FUSE_PE=0: unfused (A/B)
+    static const bool fuse12 = [] { const char* e = getenv("ST_FUSE_PE"); return !(e && e[0] == '0'); }();
+    if (fuse12 && H == 64 && W == 64 && !(((uintptr_t)cost_maps | (uintptr_t)weights[2]) & 15)) {
+        ST_TRY(st_patch_conv12(cost_maps, weights[0], weights[1], weights[2], weights[3], s2, M, H, W, stream));
+    } else {
+        ST_TRY(st_patch_conv1(cost_maps, weights[0], weights[1], s1, M, H, W, H1, W1, stream));
+        // 16-channel input, even width / stride / padding: pixel pairs (2x', 2x'+1) are 32 contiguous channels, so the
+        // 6x6 stride-2 pad-2 conv is read as a 6x3 conv, stride (2,1), pad (2,1) over [M, H1, W1/2, 32] with the SAME
+        // weight memory ((ky,kx,c) order) -- which makes every K step one whole 128-byte line for the LDS-DMA kernel.
+        ST_TRY(Gemm(s1, 32, weights[2], 576, s2, 32, 0, 32, 32).conv(M, H1, W1 / 2, 6, 3, 2, 1, 2, 1, H2, W2)
+                   .bias(weights[3]).act(ST_ACT_RELU).work(workspace, workspace_floats).run(stream));
+    }
     ST_TRY(Gemm(s2, 32, weights[4], 1152, s3, 64, 0, 64, 32).conv(M, H2, W2, 6, 6, 2, 2, 2, 2, H3, W3)
                .bias(weights[5]).work(workspace, workspace_floats).run(stream));
     ST_TRY(Gemm(s3, 64, weights[6], ld_f0, s4, 128, M * P, 128, 64).aux0(pe_bias, 128, 0, P).act(ST_ACT_RELU)

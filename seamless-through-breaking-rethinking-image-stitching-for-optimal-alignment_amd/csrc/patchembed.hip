@@ -1,0 +1,209 @@
+// PatchEmbed's first two convolutions per cost map in ONE kernel (encoder.py:60-95: Conv2d(1,16,6,2,2) + ReLU -> Conv2d(16,32,6,2,2) + ReLU),
+// gfx950 only.  VERDICT r4 item 2 / SURVEY.md section 7 step 5: a 64x64 cost map is 16 KiB, its first feature map (32x32x16) 64 KiB -- it never
+// has to leave the CU.
+//
+// Why only c0 + c2: unfused, c0 is an HBM-write-bound launch (537 MB of s1 per pair, 163 us) and c2 re-reads every s1 pixel pair 9 times through
+// L2 -> LDS DMA (4.8 GB per pair at N = 32 output channels per A byte: 0.60-0.65 of the fp32-MFMA peak, the weakest large launch of the path);
+// c4 (K = 1152, N = 64) already runs at 0.74-0.79 as a plain implicit GEMM and stays one.
+//
+// Work unit = HALF a cost map (output rows oy2 in [8h, 8h+8) of the 16x16x32 result = 128 GEMM rows = one 32-row MFMA tile per wave), so that
+// two workgroups fit a CU (74 KB of LDS each) and one's load / c0 phases run under the other's c2 MFMAs:
+//   P0  the 44 map rows the half needs (+ zero halo) -> LDS image [44][68]
+//   P1  c0 on v_mfma_f32_16x16x4_f32, the arithmetic of patch_conv1_mfma_kernel (same products, same order: bit-identical s1 values):
+//       20 rows x 32 columns x 16 channels of s1 -> LDS [20][36][16] (2-column zero halo; the 16-B channel chunks XOR-swizzled by
+//       bits 2-3 of the column so that the stride-2 tap reads of c2 are 2-way instead of 8-way bank conflicts)
+//   P2  c2 as an implicit GEMM [128 x 576] x [576 x 32] on v_mfma_f32_32x32x2_f32: A fragments are 16-byte LDS reads at loop-invariant
+//       per-lane offsets + literals (all 18 K steps unrolled: no address arithmetic in the loop), the weight K-steps (32 x 32 floats)
+//       stream through a 4-stage LDS ring by buffer_load ... lds, one workgroup barrier per step.  k order, MFMA pairing and the K-block
+//       fold after steps 8 and 16 are those of conv_gemm_dma_kernel on the (6x3 pixel-pair) view the unfused path runs: bit-identical s2.
+// Maps other than 64x64 take the unfused path (operators.hip).
+#include "common.h"
+#include "../../include/stitch_gfx950.h"
+
+typedef float pe_f32x16 __attribute__((ext_vector_type(16)));
+typedef float pe_f32x4 __attribute__((ext_vector_type(4)));
+typedef int pe_i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int pe_u32x4 __attribute__((ext_vector_type(4)));
+
+#define PE_OOB 0x80000000u
+#define PE_IMG_W 68                                  // 64 + 2 x 2 halo columns
+#define PE_IMG_ROWS 44
+#define PE_Y1_W 36
+#define PE_Y1_ROWS 20
+#define PE_STAGES 4
+#define PE_IMG_FLOATS (PE_IMG_ROWS * PE_IMG_W)               // 2992
+#define PE_Y1_FLOATS (PE_Y1_ROWS * PE_Y1_W * 16)             // 11520
+#define PE_LDS_BYTES ((PE_IMG_FLOATS + PE_Y1_FLOATS + PE_STAGES * 1024) * 4)
+
+__device__ __forceinline__ void pe_lds_dma16(pe_i32x4 rsrc, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory");
+}
+__device__ __forceinline__ pe_i32x4 pe_make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    pe_i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void patch_c0c2_kernel(const float* __restrict__ maps, const float* __restrict__ w0,
+                                                            const float* __restrict__ b0, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, float* __restrict__ out, int M) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    float* ring = smem;                                  // [PE_STAGES][32 n][32 k], rows of 128 B, chunk-swizzled like the GEMM's B tile
+    float* img = smem + PE_STAGES * 1024;                // [44][68]
+    float* y1 = img + PE_IMG_FLOATS;                     // [20][36][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int nunits = 2 * M;
+
+    // ---- once per workgroup: the halos that no unit ever writes
+    for (int e = tid; e < PE_IMG_ROWS * 4; e += 256) {
+        const int yl = e >> 2, c = e & 3;
+        img[yl * PE_IMG_W + (c < 2 ? c : 64 + c)] = 0.f;
+    }
+    for (int e = tid; e < PE_Y1_ROWS * 4 * 16; e += 256) {
+        const int r = e >> 6, c = (e >> 4) & 3, ch = e & 15;
+        y1[(r * PE_Y1_W + (c < 2 ? c : 32 + c)) * 16 + ch] = 0.f;
+    }
+
+    // ---- c0 operands (patch_conv1_mfma_kernel): A = pixel px of a 16-pixel tile / k slot ks, B = channel px
+    const int px = lane & 15, ks = lane >> 4;
+    float wv[9];
+    int toff[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int t = 4 * j + ks, ky = t / 6, kx = t - ky * 6;
+        wv[j] = w0[t * 16 + px];
+        toff[j] = ky * PE_IMG_W + kx + 2 * px;
+    }
+    const float bv0 = b0[px];
+
+    // ---- c2 operands
+    const int oyl = 2 * wave + (li >> 4), ox2 = li & 15;                 // the lane's GEMM row: local output row / column
+    const float* a_base = y1 + ((2 * oyl) * PE_Y1_W + 2 * ox2) * 16;
+    int aoff[6][2];                                                       // float offset of tap column kx, channel-chunk pair jb (chunk 2 jb + lh)
+#pragma unroll
+    for (int kx = 0; kx < 6; ++kx) {
+        const int q = 2 * ox2 + kx, sw = (q >> 2) & 3;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) aoff[kx][jb] = kx * 16 + (((2 * jb + lh) ^ sw) << 2);
+    }
+    const float* b_frag[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_frag[j] = ring + li * 32 + (((2 * j + lh) ^ ((li >> 1) & 7)) << 2);
+    const pe_i32x4 rsrcW = pe_make_rsrc(w2, 32u * 576u * 4u);
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
+    unsigned voffW;
+    {
+        const int row = 8 * wave + (lane >> 3);
+        voffW = (unsigned)(row * 576 + (((lane & 7) ^ ((row >> 1) & 7)) << 2)) * 4u;
+    }
+    const float bv2 = b2[li];
+
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const int m = u >> 1, h = u & 1;
+        __syncthreads();                                 // every wave is done with the previous unit's img / y1 / ring
+        // ---- weight K-steps 0..2 into the ring (they land under P0 / P1)
+#pragma unroll
+        for (int s = 0; s < PE_STAGES - 1; ++s) pe_lds_dma16(rsrcW, ring_lds + (unsigned)(s * 4096 + wave * 1024), voffW, (unsigned)s * 128u);
+        // ---- P0: map rows [32h - 6, 32h + 38) -> img (rows outside the map read zeros through the descriptor)
+        {
+            const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(maps + (size_t)m * 4096), 0, 16384, 0x00020000);
+            const int ybase = 32 * h - 6;
+            pe_u32x4 v[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = tid + 256 * k, yl = idx >> 4, x4 = (idx & 15) * 4, y = ybase + yl;
+                const unsigned off = (idx < PE_IMG_ROWS * 16 && y >= 0 && y < 64) ? (unsigned)(y * 64 + x4) * 4u : PE_OOB;
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)off, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = tid + 256 * k, yl = idx >> 4, x4 = (idx & 15) * 4;
+                if (idx < PE_IMG_ROWS * 16) {
+                    float2* dst = reinterpret_cast<float2*>(img + yl * PE_IMG_W + x4 + 2);
+                    dst[0] = make_float2(__uint_as_float(v[k].x), __uint_as_float(v[k].y));
+                    dst[1] = make_float2(__uint_as_float(v[k].z), __uint_as_float(v[k].w));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P1: c0 -> y1 rows r = 0..19 (s1 row 16h - 2 + r), 2 column tiles of 16 pixels each
+        for (int t = wave; t < 2 * PE_Y1_ROWS; t += 4) {
+            const int r = t >> 1, tx = t & 1;
+            const int iy = 16 * h - 2 + r;
+            pe_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const bool inside = iy >= 0 && iy < 32;      // wave-uniform
+            if (inside) {
+                const int base = 2 * r * PE_IMG_W + 32 * tx;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(img[base + toff[j]], wv[j], acc, 0, 0, 0);
+            }
+            // acc[rr]: pixel 16 tx + 4 ks + rr, channel px
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int q = 16 * tx + 4 * ks + rr + 2;
+                y1[(r * PE_Y1_W + q) * 16 + ((((px >> 2) ^ ((q >> 2) & 3))) << 2) + (px & 3)] = inside ? fmaxf(acc[rr] + bv0, 0.f) : 0.f;
+            }
+        }
+        // ---- P2: c2
+        pe_f32x16 acc, tot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; tot[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            // tile s has landed (this wave's piece), everybody is past step s - 1 (and, at s = 0, past P1)
+            if (s <= 15) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (s == 16) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (s + PE_STAGES - 1 < 18)
+                pe_lds_dma16(rsrcW, ring_lds + (unsigned)(((s + PE_STAGES - 1) % PE_STAGES) * 4096 + wave * 1024), voffW, (unsigned)(s + PE_STAGES - 1) * 128u);
+            const int ky = s / 3, kxp = s - 3 * ky;
+            const int st = s % PE_STAGES;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 fa = *reinterpret_cast<const float4*>(a_base + ky * (PE_Y1_W * 16) + aoff[2 * kxp + (j >> 1)][j & 1]);
+                const float4 fb = *reinterpret_cast<const float4*>(b_frag[j] + st * 1024);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+            }
+            if (s == 7 || s == 15) {                     // K-block fold of the unfused kernel (every 8 K steps = 256 k)
+                tot = tot + acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+        }
+        acc = acc + tot;
+        // ---- epilogue: bias + ReLU, rows 32 wave + 4 lh + ROW(r) of the unit, column li
+        {
+            float* o = out + ((size_t)m * 256 + 128 * h + 32 * wave + 4 * lh) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * 32] = fmaxf(fmaf(acc[r], 1.0f, bv2), 0.f);
+        }
+    }
+}
+
+// cost maps [M, 64*64] -> s2 rows [M*16*16, 32] (channels last) = ReLU(c2(ReLU(c0(map)))).
+extern "C" int st_patch_conv12(const float* cost_maps, const float* c0_w36x16, const float* c0_b, const float* c2_w32x576, const float* c2_b,
+                               float* s2, int32_t M, int32_t H, int32_t W, void* stream) {
+    if (!cost_maps || !c0_w36x16 || !c0_b || !c2_w32x576 || !c2_b || !s2 || M <= 0) return ST_EINVAL;
+    if (H != 64 || W != 64) return ST_EINVAL;            // the per-map LDS images are sized for the 512x512 configuration; callers fall back
+    if (((uintptr_t)cost_maps | (uintptr_t)c2_w32x576) & 15) return ST_EINVAL;
+    (void)hipFuncSetAttribute((const void*)patch_c0c2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PE_LDS_BYTES);
+    int G = 2 * M < 512 ? 2 * M : 512;                   // two workgroups per CU
+    hipLaunchKernelGGL(patch_c0c2_kernel, dim3(G), dim3(256), PE_LDS_BYTES, (hipStream_t)stream, cost_maps, c0_w36x16, c0_b, c2_w32x576, c2_b, s2, M);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

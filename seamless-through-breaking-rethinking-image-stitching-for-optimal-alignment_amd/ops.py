@@ -347,6 +347,12 @@ def _ws(dev):
     return ws.data_ptr(), ws.numel()
 
 
+def patch_conv12(maps, c0_w, c0_b, c2_w, c2_b, out, M, H=64, W=64):
+    """ReLU(c2(ReLU(c0(map)))) per 64x64 cost map in one launch (st_patch_conv12): maps [M, 4096] -> out [M*256, 32]."""
+    check(lib.st_patch_conv12(_pc(maps), _pc(c0_w), _pc(c0_b), _pc(c2_w), _pc(c2_b), _p(out), M, H, W, _stream()), "st_patch_conv12")
+    return out
+
+
 def cost_lookup9x9(maps, coords, out, Nq, H2, W2):
     check(lib.st_cost_lookup9x9(_p(maps), _pc(coords), _p(out), _ld(out), Nq, H2, W2, _stream()), "st_cost_lookup9x9")
     return out

@@ -631,6 +631,41 @@ def test_patch_embed_operator_ragged(ops):
     assert (out.cpu().double().view(M, P, 128) - ref).abs().max() < 1e-4
 
 
+def test_patch_conv12_fused_is_bit_identical(ops):
+    """st_patch_conv12 (PatchEmbed's c0 + ReLU + c2 + ReLU per 64x64 cost map in one launch, the first feature map kept in LDS) against the two
+    launches it replaces -- st_patch_conv1 + the (6x3 pixel-pair) st_conv_gemm of st_patch_embed on the LDS-DMA kernel: same products, same k
+    order, same K-block folds, so the [M*256, 32] result must be torch.equal (M = 300: 600 half-map units on 512 workgroups, every workgroup walks
+    more than one); both against torch fp64 (encoder.py:36-39,68-72).  A map's result does not depend on its neighbours: M = 1 and M = 3 (fewer
+    units than workgroup slots, odd counts) must reproduce the first maps of the big launch bit for bit (the unfused GEMM picks other kernels
+    at such row counts, so it is not the yardstick there)."""
+    M = 300
+    cm = torch.randn(M, 1, 64, 64, generator=g(21)) * 3
+    mk = lambda *s, sc=0.1, seed=0: torch.randn(*s, generator=g(seed)) * sc          # noqa: E731
+    c0, b0, c2, b2 = mk(16, 1, 6, 6, seed=2), mk(16, seed=3), mk(32, 16, 6, 6, seed=4, sc=0.05), mk(32, seed=5)
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(cm.double(), c0.double(), b0.double(), stride=2, padding=2)), c2.double(), b2.double(), stride=2, padding=2))
+    ref = ref.permute(0, 2, 3, 1).reshape(M * 256, 32)
+    w0, w2 = dev(c0.reshape(16, 36).t()), pack_conv_w(c2)
+    maps = dev(cm.reshape(M, 4096))
+    s1 = torch.empty(M * 32 * 32, 16, device="cuda")
+    ops.patch_conv1(maps, w0, dev(b0), s1, M, 64, 64, 32, 32)
+    two = torch.empty(M * 256, 32, device="cuda")
+    ops.conv_gemm(s1.view(-1, 32), w2, two, geom=(M, 32, 16, 6, 3, 2, 1, 2, 1), bias=dev(b2), act="relu")
+    one = torch.full((M * 256, 32), float("nan"), device="cuda")
+    ops.patch_conv12(maps, w0, dev(b0), w2, dev(b2), one, M)
+    assert (two.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, two), (one - two).abs().max().item()
+    for m in (1, 3):
+        few = torch.full((m * 256, 32), float("nan"), device="cuda")
+        ops.patch_conv12(maps[:m].contiguous(), w0, dev(b0), w2, dev(b2), few, m)
+        assert torch.equal(few, one[:m * 256]), m
+    again = torch.empty_like(one)
+    ops.patch_conv12(maps, w0, dev(b0), w2, dev(b2), again, M)
+    assert torch.equal(again, one)
+    with pytest.raises(ops.StitchErrorBase):
+        ops.patch_conv12(maps, w0, dev(b0), w2, dev(b2), one, M, 32, 64)              # only the 64x64 configuration is built
+
+
 # ---------------------------------------------------------------- LDS-DMA pipelined GEMM kernels (tile 12 / 13 / 14)
 @pytest.mark.parametrize("tile,Co", [(12, 130), (13, 130), (14, 24)])
 @pytest.mark.parametrize("geo", [dict(kh=3, kw=3, p=(1, 1), C=64, split=0), dict(kh=1, kw=5, p=(0, 2), C=384, split=3),
