@@ -2052,6 +2052,16 @@ extern "C" int st_abi_gemm_desc_size(void) { return (int)sizeof(st_gemm_desc); }
 // and after (phase 1) the kernels of every st_conv_gemm are enqueued -- including the launches made by the
 // operator-level entry points -- so the caller can record HIP events on `stream`.  NULL (default) = off.
 
+// launches of the family that live in other translation units (csrc/patchembed.hip) report themselves through this: phase 0 before the
+// launch, 1 after it (also records the plan of the calling thread: kernel id, tile, split-K, persistent)
+bool st_internal_observe(const st_gemm_desc* od, void* stream, int phase, int plan_kernel) {
+    if (phase == 1) { g_last_plan[0] = plan_kernel; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 1; }
+    st_gemm_observer_fn obs = g_observer;
+    if (!obs) return false;
+    obs(od, stream, phase, g_observer_user);
+    return true;
+}
+
 extern "C" int st_set_gemm_observer(void* callback, void* user) {
     g_observer = (st_gemm_observer_fn)callback;
     g_observer_user = user;

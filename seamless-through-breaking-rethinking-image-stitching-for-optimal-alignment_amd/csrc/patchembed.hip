@@ -19,6 +19,9 @@
 // Maps other than 64x64 take the unfused path (operators.hip).
 #include "common.h"
 #include "../../include/stitch_gfx950.h"
+#include <string.h>
+
+bool st_internal_observe(const st_gemm_desc* od, void* stream, int phase, int plan_kernel);      // csrc/gemm.hip
 
 typedef float pe_f32x16 __attribute__((ext_vector_type(16)));
 typedef float pe_f32x4 __attribute__((ext_vector_type(4)));
@@ -203,7 +206,16 @@ extern "C" int st_patch_conv12(const float* cost_maps, const float* c0_w36x16, c
     if (((uintptr_t)cost_maps | (uintptr_t)c2_w32x576) & 15) return ST_EINVAL;
     (void)hipFuncSetAttribute((const void*)patch_c0c2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PE_LDS_BYTES);
     int G = 2 * M < 512 ? 2 * M : 512;                   // two workgroups per CU
+    // the profiling observer sees the launch as c2's GEMM (M*256 x 32 x 576: its FLOPs; c0's 9.7 GFLOP per pair ride along uncounted) reading the
+    // cost maps (Cin = 1) -- the A + W + C byte formula of the tools then counts what this kernel really moves
+    st_gemm_desc od;
+    memset(&od, 0, sizeof(od));
+    od.a = cost_maps; od.w = c2_w32x576; od.c = s2; od.bias = c2_b;
+    od.M = M * 256; od.N = 32; od.K = 576; od.H = 64; od.W = 64; od.Cin = 1; od.ldx = 1; od.ldw = 576; od.ldc = 32;
+    od.kh = od.kw = 6; od.sh = od.sw = 2; od.ph = od.pw = 2; od.Ho = od.Wo = 16; od.batch = 1; od.alpha = 1.f; od.act = ST_ACT_RELU;
+    st_internal_observe(&od, stream, 0, 7);
     hipLaunchKernelGGL(patch_c0c2_kernel, dim3(G), dim3(256), PE_LDS_BYTES, (hipStream_t)stream, cost_maps, c0_w36x16, c0_b, c2_w32x576, c2_b, s2, M);
+    st_internal_observe(&od, stream, 1, 7);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -22,7 +22,7 @@ import sys
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 
 FAMILY = {0: "skinny_gemm_kernel", 1: "narrow_conv_kernel", 2: "conv_gemm_kernel", 3: "conv_gemm_dma_kernel", 4: "rowstream_gemm_kernel", 5: "rowchain128_kernel",
-          6: "rowmlp128_kernel"}
+          6: "rowmlp128_kernel", 7: "patch_c0c2_kernel"}
 PEAK = 157.3
 
 
@@ -169,7 +169,7 @@ def join(out_csv, launches_json, fetch_csv, write_csv_path):
         rows = []
         for r in csv.DictReader(open(path)):
             k = re.sub(r"\(.*", "", r["Kernel_Name"]).strip()
-            if any(s in k for s in ("conv_gemm", "skinny_gemm", "narrow_conv", "splitk_reduce", "rowstream_gemm", "rowchain128", "rowmlp128")):
+            if any(s in k for s in ("conv_gemm", "skinny_gemm", "narrow_conv", "splitk_reduce", "rowstream_gemm", "rowchain128", "rowmlp128", "patch_c0c2")):
                 rows.append((int(r.get("Dispatch_Id", len(rows))), k, float(r["Counter_Value"])))
         rows.sort()
         return rows
