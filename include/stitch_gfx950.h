@@ -330,7 +330,8 @@ int st_morph_open19(const float* mask, float* out, void* scratch_u8x2, int32_t N
 /* PatchEmbed.forward (encoder.py:60-95; patch 8, 'single', linear PE): cost maps [M,H,W] -> tokens
  * [M*P,128], P = ceil(H/8)*ceil(W/8).  weights (host array of 11 device pointers): c0_w[36,16] c0_b
  * c2_w[32,576] c2_b c4_w[64,1152] c4_b f0_w[128,ld_f0] (cols 0..63) f2_w[128,128] f2_b ln_w ln_b;
- * pe_bias [P,128] = f0_w[:,64:] . sinePE(pos) + f0_b.  scratch rows: s1 16, s2 32, s3 64, s4 128 wide. */
+ * pe_bias [P,128] = f0_w[:,64:] . sinePE(pos) + f0_b.  scratch rows: s1 16, s2 32, s3 64, s4 128 wide.
+ * 64x64 maps run the first two convs as st_patch_conv12 (s1 stays on the CU): s1 may then be NULL. */
 int st_patch_embed(const float* cost_maps, const float* const* weights, int32_t ld_f0, const float* pe_bias,
                    float* s1, float* s2, float* s3, float* s4, float* tokens, int32_t M, int32_t H, int32_t W,
                    void* workspace, int64_t workspace_floats, void* stream);

@@ -80,17 +80,20 @@ int st_morph_open19(const float* mask, float* out, void* scratch_u8x2, int32_t N
 // pe_bias = W0[:,64:] . pe(pos) + b0.  weights (host array of 11 device pointers):
 //   0 c0_w[36,16] 1 c0_b | 2 c2_w[32,576] 3 c2_b | 4 c4_w[64,1152] 5 c4_b | 6 f0_w[128,ld_f0 (cols 0..63 used)]
 //   | 7 f2_w[128,128] 8 f2_b | 9 ln_w 10 ln_b
-// scratch: s1 [M*H/2*W/2,16], s2 [M*H/4*W/4,32], s3 [M*P,64], s4 [M*P,128]; tokens [M*P,128], P = (H/8)*(W/8).
+// scratch: s1 [M*H/2*W/2,16] (may be NULL for 64x64 maps with ST_FUSE_PE != 0: st_patch_conv12 keeps it on the CU; ST_EINVAL if the unfused launches would need it), s2 [M*H/4*W/4,32],
+// s3 [M*P,64], s4 [M*P,128]; tokens [M*P,128], P = (H/8)*(W/8).
 int st_patch_embed(const float* cost_maps, const float* const* weights, int32_t ld_f0, const float* pe_bias, float* s1,
                    float* s2, float* s3, float* s4, float* tokens, int32_t M, int32_t H, int32_t W, void* workspace,
                    int64_t workspace_floats, void* stream) {
-    if (!cost_maps || !weights || !pe_bias || !s1 || !s2 || !s3 || !s4 || !tokens || M <= 0 || H <= 0 || W <= 0)
+    if (!cost_maps || !weights || !pe_bias || !s2 || !s3 || !s4 || !tokens || M <= 0 || H <= 0 || W <= 0)
         return ST_EINVAL;
     const int Hp = (H + 7) / 8 * 8, Wp = (W + 7) / 8 * 8;      // zero pad to the patch size (encoder.py:63-66)
     const int H1 = Hp / 2, W1 = Wp / 2, H2 = Hp / 4, W2 = Wp / 4, H3 = Hp / 8, W3 = Wp / 8, P = H3 * W3;
     // the first two convs of a 64x64 map in one launch, s1 kept on the CU (csrc/patchembed.hip; bit-identical).  ST_FUSE_PE=0: unfused (A/B)
     static const bool fuse12 = [] { const char* e = getenv("ST_FUSE_PE"); return !(e && e[0] == '0'); }();
-    if (fuse12 && H == 64 && W == 64 && !(((uintptr_t)cost_maps | (uintptr_t)weights[2]) & 15)) {
+    const bool can_fuse = fuse12 && H == 64 && W == 64 && !(((uintptr_t)cost_maps | (uintptr_t)weights[2]) & 15);
+    if (!s1 && !can_fuse) return ST_EINVAL;              // s1 == NULL: the caller counts on the fused launch (it saves the 64 KiB-per-map scratch)
+    if (can_fuse) {
         ST_TRY(st_patch_conv12(cost_maps, weights[0], weights[1], weights[2], weights[3], s2, M, H, W, stream));
     } else {
         ST_TRY(st_patch_conv1(cost_maps, weights[0], weights[1], s1, M, H, W, H1, W1, stream));

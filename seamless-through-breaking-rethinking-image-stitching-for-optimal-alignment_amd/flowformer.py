@@ -39,6 +39,7 @@ FUSE_CHAIN = os.environ.get("ST_FUSE_CHAIN", "1") != "0"        # the latent lay
 # latent layers); joined by an event before the first vertical layer (context) and by a stream join before the refinement loop.  Captured
 # into the forward's hipGraph as a parallel branch.  Same kernels, same operands: bit-identical.  Measured in round 5 (section 5 of DESIGN.md).
 FORK = os.environ.get("ST_FORK", "0") == "1"
+FUSE_PE = os.environ.get("ST_FUSE_PE", "1") != "0"              # PatchEmbed c0 + c2 per cost map in one launch (csrc/patchembed.hip; the library reads the same switch)
 _SIDE = {}
 
 
@@ -321,7 +322,9 @@ class FlowFormer(ParamTree):
             tab = _new(P, 128, dev)
             ops.conv_gemm(tab_in, pe["f0"][0][:, 64:], tab, bias=pe["f0"][1])
             self._const[key] = tab
-        s1, s2 = _new(M * H1 * W1, 16, dev), _new(M * H2p * W2p, 32, dev)
+        # 64x64 maps: the first two convs run as one launch that keeps the first feature map (64 KiB per map, 537 MB per pair) on the CU
+        s1 = None if (H2 == 64 and W2 == 64 and FUSE_PE) else _new(M * H1 * W1, 16, dev)
+        s2 = _new(M * H2p * W2p, 32, dev)
         s3, s4, f = _new(M * P, 64, dev), _new(M * P, 128, dev), _new(M * P, 128, dev)
         ops.patch_embed(cost_maps, pe["embed11"], pe["f0"][0].stride(0), self._const[key], s1, s2, s3, s4, f, M, H2, W2)
         return f, P

@@ -360,7 +360,7 @@ def cost_lookup9x9(maps, coords, out, Nq, H2, W2):
 
 def patch_embed(cost_maps, weights11, ld_f0, pe_bias, s1, s2, s3, s4, tokens, M, H, W):
     arr = (C.c_void_p * 11)(*[w.data_ptr() for w in weights11])
-    check(lib.st_patch_embed(_pc(cost_maps), arr, ld_f0, _pc(pe_bias), _pc(s1), _pc(s2), _pc(s3), _pc(s4), _pc(tokens),
+    check(lib.st_patch_embed(_pc(cost_maps), arr, ld_f0, _pc(pe_bias), _pc(s1) if s1 is not None else None, _pc(s2), _pc(s3), _pc(s4), _pc(tokens),
                              M, H, W, *_ws(cost_maps.device), _stream()), "st_patch_embed")
     return tokens
 
