@@ -39,6 +39,7 @@ FUSE_CHAIN = os.environ.get("ST_FUSE_CHAIN", "1") != "0"        # the latent lay
 # latent layers); joined by an event before the first vertical layer (context) and by a stream join before the refinement loop.  Captured
 # into the forward's hipGraph as a parallel branch.  Same kernels, same operands: bit-identical.  Measured in round 5 (section 5 of DESIGN.md).
 FORK = os.environ.get("ST_FORK", "0") == "1"
+FORK_ENC = os.environ.get("ST_FORK_ENC", "0") == "1"           # experiment: flow_encode of an iteration on a side stream beside cost lookup + token chain (which fill half the CUs)
 FUSE_PE = os.environ.get("ST_FUSE_PE", "1") != "0"              # PatchEmbed c0 + c2 per cost map in one launch (csrc/patchembed.hip; the library reads the same switch)
 _SIDE = {}
 
@@ -512,7 +513,7 @@ class FlowFormer(ParamTree):
                     cor1=_new(R, 256, dev), corflo=_new(R, 256, dev), flo1=_new(R, 128, dev),
                     vT=torch.empty((B, 128, N), device=dev), zbuf=_new(R, 128, dev), fh=_new(R, 256, dev))
 
-    def _update_block(self, S, coords1, attn, gru_tab, B, H1, W1):
+    def _update_block(self, S, coords1, attn, gru_tab, B, H1, W1, enc_done=None):
         """GMAUpdateBlock.forward (gru.py:322-334) without the mask head: BasicMotionEncoder (gru.py:246-254), GMA
         aggregate (gma.py:102-115), SepConvGRU (gru.py:44-59), flow head (gru.py:5-13); coords1 += delta_flow
         (decoder.py:329).  Reads S['corr'] (cost_forward | cost_global), updates S['hxA'][:, :128] (net) and coords1."""
@@ -521,7 +522,10 @@ class FlowFormer(ParamTree):
         hxA, hxB, corr = S["hxA"], S["hxB"], S["corr"]
         g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
         ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu")
-        ops.flow_encode(coords1, D["convf1"][0], D["convf1"][1], S["flo1"], hxA[:, 254:256], B, H1, W1)      # :321, gru.py:251,254
+        if enc_done is not None:
+            torch.cuda.current_stream().wait_event(enc_done)         # ST_FORK_ENC: already enqueued on the side stream by _decoder
+        else:
+            ops.flow_encode(coords1, D["convf1"][0], D["convf1"][1], S["flo1"], hxA[:, 254:256], B, H1, W1)      # :321, gru.py:251,254
         # convc2 (384 tiles) and convf2 (128 tiles) are independent and ready together: one launch, two workgroups per CU, no
         # split-K slabs (gru.py:252-253)
         if PAIR_CONVS:
@@ -585,10 +589,19 @@ class FlowFormer(ParamTree):
         coords1 = _new(R, 2, dev)
         ops.coords_grid(coords1, B, H1, W1)
         for it in range(iters):
+            enc_done = None
+            if FORK_ENC:
+                cur = torch.cuda.current_stream()
+                side = _side_stream(cur)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ops.flow_encode(coords1, D["convf1"][0], D["convf1"][1], S["flo1"], S["hxA"][:, 254:256], B, H1, W1)
+                    enc_done = torch.cuda.Event()
+                    enc_done.record(side)
             ops.cost_lookup9x9(cost_maps, coords1, S["corr"], R, H1, W1)                              # decoder.py:291
             # flow_token_encoder + cost-memory cross attention + FFN: one fused launch (decoder.py:305-312)
             ops.decoder_token_chain(S["corr"], coords1, kv, D["chain16"], R, nl)
-            self._update_block(S, coords1, attn, gru_tab, B, H1, W1)
+            self._update_block(S, coords1, attn, gru_tab, B, H1, W1, enc_done=enc_done)
             if trace is not None:
                 trace.append(dict(coords1=coords1.clone(), net=S["hxA"][:, :128].clone(), corr=S["corr"].clone()))
         # mask head + convex upsampling, last iteration only (gru.py:315-318,333; decoder.py:214-225)
