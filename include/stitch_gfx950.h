@@ -71,6 +71,17 @@ typedef struct st_gemm_desc {
                               (encoder.py:359-369 evaluated for (f2, f1)) and costs a second store instead of a second product */
     int32_t ld_ct;
     int32_t reserved2;     /* must be 0 */
+    int32_t split3;        /* 0: a / w are fp32 (everything above).  1: EXACT-SPLIT operands on the bf16 matrix cores (csrc/gemm_split3.h):
+                              a, w (and a2) point to THREE bf16 planes hi, mid, lo with x == hi + mid + lo exactly (st_split3_pack or a
+                              producing kernel's epilogue), each blocked by 32-channel chunks: plane = [C / 32][rows][32] bf16, the planes
+                              a_plane_stride / w_plane_stride ELEMENTS apart; a_rows = rows per chunk of the A planes (all pixels B*H*W of the
+                              activation, >= what the geometry addresses), w_rows = rows per chunk of the W planes (>= N; W chunks follow the
+                              K order (ky, kx, c / 32)).  ldx / ldw are ignored; batch strides are bf16 elements inside each plane.  The six
+                              products hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi are accumulated in fp32 (dropped terms <= 2^-23 |a||b|);
+                              epilogue, split-K and outputs exactly as the fp32 kernels.  Cin % 32 == 0; tile_cfg 0 = auto, 31: 128x128,
+                              32: 128x64, 33: 64x128, 34: 64x64; c_t and a_ln are rejected.                                                 */
+    int32_t reserved3;     /* must be 0 */
+    int64_t a_plane_stride, w_plane_stride, a_rows, w_rows;
 } st_gemm_desc;
 
 /* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.
@@ -78,6 +89,12 @@ typedef struct st_gemm_desc {
  *   gru.py:44-59,246-254,5-13 (SepConvGRU, motion encoder, heads), gma.py:54-76,102-115,
  *   twins.py:253-392,587-680 (q/k/v/proj/sr/MLP), core/UDIS2/Homography/network.py:18-46,103-137. */
 int st_conv_gemm(const st_gemm_desc* desc, void* stream);
+
+/* fp32 rows [rows, ldx] (C columns, C % 32 == 0) -> the three blocked bf16 planes st_gemm_desc.split3 consumes:
+ * planes[p * plane_stride + ((c / 32) * chunk_rows + row) * 32 + c % 32], p = 0 (hi), 1 (mid), 2 (lo); x == hi + mid + lo exactly
+ * (+-inf / NaN stay in hi alone).  Used once per weight at pack time and for activations no split3-emitting kernel produced.
+ * Operands of: gru.py:44-59,246-254, gma.py:102-115, encoder.py:359-369.                                                   */
+int st_split3_pack(const float* x, void* planes, int64_t rows, int32_t C, int64_t ldx, int64_t plane_stride, int64_t chunk_rows, void* stream);
 
 /* Two independent contractions in ONE launch: workgroups of both descriptors share the grid, so two mid-size convs that are
  * ready together (BasicMotionEncoder's convc2 and convf2, gru.py:252-253) fill the chip without split-K slabs or a second

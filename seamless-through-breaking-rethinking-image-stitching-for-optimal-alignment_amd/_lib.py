@@ -36,7 +36,8 @@ class GemmDesc(C.Structure):
            ("c2", C.c_void_p), ("ldc2", C.c_int32), ("a_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("reserved0", C.c_int32),
            ("batch_stride_aux1", C.c_int64), ("dh", C.c_int32), ("dw", C.c_int32), ("a_ln", C.c_int32), ("a_ln_eps", C.c_float),
            ("a2", C.c_void_p), ("a2_channels", C.c_int32), ("reserved1", C.c_int32),
-           ("c_t", C.c_void_p), ("ld_ct", C.c_int32), ("reserved2", C.c_int32)]
+           ("c_t", C.c_void_p), ("ld_ct", C.c_int32), ("reserved2", C.c_int32), ("split3", C.c_int32), ("reserved3", C.c_int32)]
+        + [(n, C.c_int64) for n in ("a_plane_stride", "w_plane_stride", "a_rows", "w_rows")]
     )
 
 

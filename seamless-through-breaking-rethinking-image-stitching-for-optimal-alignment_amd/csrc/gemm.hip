@@ -876,6 +876,8 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_pair_kernel(const st_gemm_p
     conv_gemm_dma_body<WM, WN, TM, TN, STAGES, false>(second ? g.d[1] : g.d[0], second ? (int)blockIdx.x - g.tiles0 : (int)blockIdx.x);
 }
 
+#include "gemm_split3.h"
+
 // ---------------------------------------------------------------------------------------------
 // Row-streaming GEMM for the short-K linears (K = 64 / 128: the Twins / latent / vertical-layer linears at
 // M = 32768 ... 524288: twins.py:253-304,336-392,785, encoder.py:156-172, crossattentionlayer.py:37-56).  Those shapes are
@@ -1762,7 +1764,9 @@ static int launch_rowstream(const st_gemm_desc& d, int max_cps, hipStream_t s) {
     return ST_OK;
 }
 
+static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream);
 static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
+    if (desc->split3) return conv_gemm_split3_launch(desc, stream);
     st_gemm_desc d = *desc;
     if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
     if (d.kh <= 0 || d.kw <= 0 || d.K != d.kh * d.kw * d.Cin) return ST_EINVAL;
@@ -1770,7 +1774,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
-    if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0) return ST_EINVAL;
+    if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0 || d.reserved3 != 0) return ST_EINVAL;
     if (d.c_t && (d.epi != ST_EPI_STORE || (d.M & 3) || (d.ld_ct & 3) || d.ld_ct < d.M || ((uintptr_t)d.c_t & 15) || d.split_k > 1 || d.a_ln ||
                   (int64_t)d.N * d.ld_ct * 4 >= ((int64_t)1 << 31)))
         return ST_EINVAL;
@@ -1940,6 +1944,101 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
     }
 }
 
+// ---- split3 (csrc/gemm_split3.h): a / w are three blocked bf16 planes -------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int STAGES, int DIAG = 0>
+static int launch_split3(const st_gemm_desc& d, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    const int batch = d.batch > 0 ? d.batch : 1;
+    const size_t lds = (size_t)STAGES * 3 * (BM + BN) * 64;
+    auto k = conv_gemm_split3_kernel<WM, WN, TM, TN, STAGES, DIAG>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(ntm * ntn, 1, d.split_k > 1 ? d.split_k : batch), dim3(512), lds, s, d);
+    if (d.split_k > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(((size_t)d.M * d.N + 255) / 256), dim3(256), 0, s, d);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
+    st_gemm_desc d = *desc;
+    if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
+    if (d.kh <= 0 || d.kw <= 0 || d.K != d.kh * d.kw * d.Cin || d.Cin % 32) return ST_EINVAL;
+    if (d.Ho <= 0 || d.Wo <= 0 || d.M % (d.Ho * d.Wo)) return ST_EINVAL;
+    if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
+    if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
+    if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
+    if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0 || d.reserved3 != 0 || d.c_t || d.a_ln) return ST_EINVAL;
+    if (d.a_plane_stride <= 0 || d.w_plane_stride <= 0 || d.a_rows <= 0 || d.w_rows < d.N) return ST_EINVAL;
+    if (((uintptr_t)d.a & 15) || ((uintptr_t)d.w & 15) || (d.a_plane_stride & 7) || (d.w_plane_stride & 7) || (d.batch_stride_a & 7) ||
+        (d.batch_stride_w & 7))
+        return ST_EINVAL;
+    if (d.a2 && (d.a2_channels <= 0 || d.a2_channels % 32 || d.a2_channels > d.Cin || d.batch > 1 || ((uintptr_t)d.a2 & 15))) return ST_EINVAL;
+    const bool plain_mat = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && (int64_t)d.H * d.W == d.M &&
+                           (int64_t)d.Ho * d.Wo == d.M;
+    const int64_t nimg = d.M / ((int64_t)d.Ho * d.Wo), in_rows = plain_mat ? d.M : nimg * d.H * d.W;
+    if (in_rows > d.a_rows) return ST_EINVAL;
+    // extents (bytes) from the plane-0 base to the end of plane 2; the 32-bit buffer offsets and the out-of-range sentinel need < 2 GiB
+    const int64_t ab = 2 * (2 * d.a_plane_stride + (int64_t)(d.Cin / 32) * d.a_rows * 32);
+    const int64_t wb = 2 * (2 * d.w_plane_stride + (int64_t)(d.K / 32) * d.w_rows * 32);
+    if (ab >= (int64_t)ST_OOB || wb >= (int64_t)ST_OOB) return ST_EINVAL;
+    int64_t ldmax = d.ldc > d.N ? d.ldc : d.N;
+    if (d.aux0 && d.ld_aux0 > ldmax) ldmax = d.ld_aux0;
+    if (d.aux1 && d.ld_aux1 > ldmax) ldmax = d.ld_aux1;
+    if (d.aux2 && d.ld_aux2 > ldmax) ldmax = d.ld_aux2;
+    if (d.c2 && d.ldc2 > ldmax) ldmax = d.ldc2;
+    if (((int64_t)d.M + 256) * ldmax * 4 >= ((int64_t)1 << 31)) return ST_EINVAL;
+    d.a_bytes = (uint32_t)ab; d.w_bytes = (uint32_t)wb;
+    const int batch = d.batch > 0 ? d.batch : 1;
+    int cfg = d.tile_cfg;
+    if (cfg == 0) cfg = 31;
+    static const int bms[7] = {0, 128, 128, 64, 64, 128, 64}, bns[7] = {0, 128, 64, 128, 64, 64, 64};
+    if (cfg < 31 || cfg > 36) return ST_EINVAL;
+    const long tiles = (long)((d.M + bms[cfg - 30] - 1) / bms[cfg - 30]) * ((d.N + bns[cfg - 30] - 1) / bns[cfg - 30]) * batch;
+    int split = d.split_k;
+    if (split == 0) {
+        split = 1;
+        if (batch == 1 && d.workspace && d.K >= 512 && tiles < 256) split = (int)((256 + tiles - 1) / tiles);
+        if (split > d.K / 256) split = d.K / 256;
+        if (split > 16) split = 16;
+        if (split < 1) split = 1;
+        while (split > 1 && (int64_t)split * d.M * d.N > d.workspace_floats) --split;
+    }
+    if (split > 1) {
+        if (batch != 1 || !d.workspace || (int64_t)split * d.M * d.N > d.workspace_floats) return ST_EINVAL;
+        const int nkt = d.K / 32, per = (nkt + split - 1) / split;
+        split = (nkt + per - 1) / per;                     // no empty slice
+    }
+    d.split_k = split;
+    g_last_plan[0] = 7; g_last_plan[1] = cfg; g_last_plan[2] = split; g_last_plan[3] = 0;
+    hipStream_t s = (hipStream_t)stream;
+    // timing experiments (tools/split3_probe.py --diag): ST_SPLIT3_DIAG=1 consumers skip the MFMAs, 2 loaders skip the DMA; results are garbage
+    static const int diag = [] { const char* e = getenv("ST_SPLIT3_DIAG"); return e ? atoi(e) : 0; }();
+    if (diag == 1) return cfg == 34 ? launch_split3<2, 2, 1, 1, 3, 1>(d, s) : cfg == 32 ? launch_split3<2, 2, 2, 1, 4, 1>(d, s) : launch_split3<2, 2, 2, 2, 3, 1>(d, s);
+    if (diag == 2) return cfg == 34 ? launch_split3<2, 2, 1, 1, 3, 2>(d, s) : cfg == 32 ? launch_split3<2, 2, 2, 1, 4, 2>(d, s) : launch_split3<2, 2, 2, 2, 3, 2>(d, s);
+    switch (cfg) {
+        case 31: return launch_split3<2, 2, 2, 2, 3>(d, s);
+        case 32: return launch_split3<2, 2, 2, 1, 4>(d, s);
+        case 33: return launch_split3<2, 2, 1, 2, 4>(d, s);
+        case 35: return launch_split3<2, 2, 2, 1, 3>(d, s);
+        case 36: return launch_split3<2, 2, 1, 1, 4>(d, s);
+        default: return launch_split3<2, 2, 1, 1, 3>(d, s);
+    }
+}
+
+// fp32 [rows, ldx] (C columns) -> three blocked bf16 planes [C/32][chunk_rows][32], plane_stride elements apart (csrc/gemm_split3.h)
+extern "C" int st_split3_pack(const float* x, void* planes, int64_t rows, int32_t C, int64_t ldx, int64_t plane_stride, int64_t chunk_rows,
+                              void* stream) {
+    if (!x || !planes || rows <= 0 || C <= 0 || C % 32 || ldx < C || (ldx & 3) || chunk_rows < rows || ((uintptr_t)x & 15) ||
+        ((uintptr_t)planes & 15) || (plane_stride & 7) || plane_stride < (int64_t)(C / 32) * chunk_rows * 32)
+        return ST_EINVAL;
+    const long long n = (long long)rows * (C / 8);
+    hipLaunchKernelGGL(split3_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)planes, (long long)rows, (int)C,
+                       (long long)ldx, (long long)plane_stride, (long long)chunk_rows);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 // Checks + buffer extents of a descriptor that must run on the plain (non-persistent, unsplit) 64x64 LDS-DMA kernel.
 static int pair_member_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
     d = *desc;
@@ -1949,7 +2048,7 @@ static int pair_member_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
     if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
-    if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0 || d.c_t || d.a_ln || d.batch > 1 || d.split_k > 1 || (d.tile_cfg != 0 && d.tile_cfg != 13)) return ST_EINVAL;
+    if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0 || d.reserved3 != 0 || d.split3 || d.c_t || d.a_ln || d.batch > 1 || d.split_k > 1 || (d.tile_cfg != 0 && d.tile_cfg != 13)) return ST_EINVAL;
     if (d.a2 && (d.a2_channels <= 0 || d.a2_channels % 32 || d.a2_channels > d.Cin || ((uintptr_t)d.a2 & 15))) return ST_EINVAL;
     if (((uintptr_t)d.a & 15) || ((uintptr_t)d.w & 15) || (d.ldx & 3) || (d.ldw & 3)) return ST_EINVAL;
     const bool plain_mat = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && (int64_t)d.H * d.W == d.M &&
