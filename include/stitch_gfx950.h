@@ -82,6 +82,16 @@ typedef struct st_gemm_desc {
                               32: 128x64, 33: 64x128, 34: 64x64; c_t and a_ln are rejected.                                                 */
     int32_t reserved3;     /* must be 0 */
     int64_t a_plane_stride, w_plane_stride, a_rows, w_rows;
+    void* c_planes;        /* optional (any kernel of the family, fp32 or split3 operands): the result ALSO leaves as three blocked bf16 planes
+                              (the operand format of a split3 consumer), written by the epilogue that produced it -- no separate pass, no split
+                              work in any K loop.  Element (m, n) goes to plane p at
+                                  c_planes[p * c_plane_stride + (((c_plane_col0 + n) / 32) * c_plane_rows + c_plane_row0 + z * c_plane_batch_rows + m) * 32
+                                           + (c_plane_col0 + n) % 32]            (z = batch index)
+                              In ST_EPI_ZR mode the planes receive the SECOND output (c2 = r*h, column n - N/2).  M % 32 == 0 and
+                              c_plane_col0 % 32 == 0 are required; c_no_f32 = 1 skips the fp32 store of that output (its c / c2 pointer must
+                              still be valid: split-K partial sums and the z half are unaffected).                                        */
+    int64_t c_plane_stride, c_plane_rows, c_plane_batch_rows;
+    int32_t c_plane_col0, c_plane_row0, c_no_f32, reserved4;
 } st_gemm_desc;
 
 /* fp32 MFMA implicit GEMM: nn.Linear / F.conv2d / einsum on the path, e.g.
@@ -264,6 +274,13 @@ int st_flow_from_coords(const float* coords1, float* flow4, int32_t ld4, float* 
  * columns 0..1 of rows of stride ld2 (gru.py:254 cat([out, flow])).  Co % 4 == 0.                                 */
 int st_flow_encode(const float* coords1, const float* w98, const float* bias, float* out, int32_t ldo, float* flow2,
                    int32_t ld2, int32_t B, int32_t H, int32_t W, int32_t Co, void* stream);                             /* decoder.py:321   */
+/* The same, ALSO leaving both results as blocked bf16 planes (st_gemm_desc.split3 operand format, planes `*_pstride` elements apart,
+ * `*_prows` rows per 32-channel chunk): out_planes [3][Co/32][out_prows][32]; channels flow_col, flow_col + 1 (flow_col even) of flow_planes
+ * (may be NULL).  Co % 32 == 0.  Replaces gru.py:251,254 for a split3 consumer of gru.py:252-253 / 44-59.                          */
+int st_flow_encode_split3(const float* coords1, const float* w98, const float* bias, float* out, int32_t ldo, float* flow2,
+                          int32_t ld2, int32_t B, int32_t H, int32_t W, int32_t Co, void* out_planes, int64_t out_pstride,
+                          int64_t out_prows, void* flow_planes, int64_t flow_pstride, int64_t flow_prows, int32_t flow_col,
+                          void* stream);
 /* encode_flow_token + bilinear_sampler (decoder.py:242-260, core/utils/utils.py:62-76).              */
 int st_cost_lookup(const float* maps, const float* coords, float* out, int32_t ldo, int32_t Nq, int32_t H2,
                    int32_t W2, int32_t r, void* stream);
@@ -366,6 +383,21 @@ int st_gma_aggregate(const float* attn, const float* mf, int32_t ld_mf, const fl
 int st_sepconv_gru(float* hxA, float* hxB, int32_t ld, float* zbuf, const float* tab1, const float* tab2,
                    int32_t ld_tab, const float* w_zr1, const float* w_q1, const float* w_zr2, const float* w_q2,
                    int32_t B, int32_t H, int32_t W, void* workspace, int64_t workspace_floats, void* stream);
+/* The same two operators on EXACT-SPLIT operands (st_gemm_desc.split3): every contraction operand is three blocked bf16 planes
+ * [C/32][prows][32] (`*_pstride` elements apart) that the producing kernels' epilogues wrote, the six partial products run on the bf16
+ * matrix cores with fp32 accumulation (error <= the fp32 chain's, tools/split3_probe.py), epilogue operands and results stay fp32.
+ * st_gma_aggregate_split3 (gma.py:102-115): attn_planes [3][N/32][B*N][32] = st_split3_pack of attn, once per pass; vT_planes scratch
+ * [3][N/32][B*128][32]; the result also goes to columns out_col..out_col+127 of out_planes.
+ * st_sepconv_gru_split3 (gru.py:44-59): hxA_planes / hxB_planes image hxA = [h | x] and hxB = [r*h | -] (ld channels, ld % 32 == 0);
+ * r*h exists only as planes; the new h goes to hxA (fp32, in place) and to columns 0..127 of hxA_planes; w_* are st_split3_pack
+ * images of the fp32 operator's weight matrices.                                                                                   */
+int st_gma_aggregate_split3(const void* attn_planes, int64_t attn_pstride, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma,
+                            float* vT, void* vT_planes, int64_t vT_pstride, float* out, int32_t ld_out, void* out_planes, int64_t out_pstride,
+                            int64_t out_prows, int32_t out_col, int32_t B, int32_t N, void* workspace, int64_t workspace_floats, void* stream);
+int st_sepconv_gru_split3(float* hxA, int32_t ld, void* hxA_planes, void* hxB_planes, int64_t pstride, int64_t prows, float* zbuf,
+                          const float* tab1, const float* tab2, int32_t ld_tab, const void* w_zr1, const void* w_q1, const void* w_zr2,
+                          const void* w_q2, int64_t w_pstride_zr, int64_t w_pstride_q, int32_t B, int32_t H, int32_t W, void* workspace,
+                          int64_t workspace_floats, void* stream);
 
 /* ---- UDIS2 composition stage (the convolutions run on st_conv_gemm with dh/dw) ------------ */
 /* F.interpolate(mode='nearest') to (oh, ow), channels-last rows, C % 4 == 0 (Composition/network.py:70).   */

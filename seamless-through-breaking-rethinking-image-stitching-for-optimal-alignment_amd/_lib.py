@@ -38,6 +38,8 @@ class GemmDesc(C.Structure):
            ("a2", C.c_void_p), ("a2_channels", C.c_int32), ("reserved1", C.c_int32),
            ("c_t", C.c_void_p), ("ld_ct", C.c_int32), ("reserved2", C.c_int32), ("split3", C.c_int32), ("reserved3", C.c_int32)]
         + [(n, C.c_int64) for n in ("a_plane_stride", "w_plane_stride", "a_rows", "w_rows")]
+        + [("c_planes", C.c_void_p)] + [(n, C.c_int64) for n in ("c_plane_stride", "c_plane_rows", "c_plane_batch_rows")]
+        + [(n, C.c_int32) for n in ("c_plane_col0", "c_plane_row0", "c_no_f32", "reserved4")]
     )
 
 

@@ -81,6 +81,27 @@ __device__ __forceinline__ float st_act(float v, int act) {
 // entry by the system's condition number (ocml's fp32 logf: T off by 4.4e-5 relative; this: 1.8e-7, tests/test_ops_gpu.py::test_tps).
 __device__ __forceinline__ float st_logf_cr(float x) { return (float)log((double)x); }
 
+// ---- exact three-way bf16 split of an fp32 value (operand format of csrc/gemm_split3.h) --------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// x -> (hi, mid, lo), x == hi + mid + lo exactly for every finite x with |x| >= 2^-110 (below that lo leaves bf16's
+// subnormal range).  +-inf / NaN stay in hi alone (mid = lo = 0): inf - inf would otherwise make the residual NaN and turn
+// inf . finite into NaN; an x that only bf16 rounding pushes to inf keeps the largest finite bf16 as hi.
+__device__ __forceinline__ void st_split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)x;
+    float hf = (float)hi;
+    if (__builtin_isinf(hf) || hf != hf) {
+        if (__builtin_isinf(x) || x != x) { mid = (__bf16)0.f; lo = (__bf16)0.f; return; }
+        hf = copysignf(3.3895313892515355e38f, x);          // 0x7F7F0000: largest finite bf16
+        hi = (__bf16)hf;
+    }
+    const float r1 = x - hf;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+
+// one value into the three planes of a blocked plane tensor (byte offset `off` inside plane 0, planes `plane_bytes` apart)
+__device__ __forceinline__ unsigned short st_bf16_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

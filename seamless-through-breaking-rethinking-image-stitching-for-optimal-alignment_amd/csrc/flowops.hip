@@ -58,7 +58,9 @@ extern "C" int st_flow_from_coords(const float* coords1, float* flow4, int32_t l
 // lane = pixel and scalar-loaded weights was latency-bound on the scalar cache: 25 us.)
 __global__ __launch_bounds__(512) void flow_encode_kernel(const float* __restrict__ coords1, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out, int ldo,
-                                                          float* __restrict__ flow2, int ld2, int H, int W, int Co) {
+                                                          float* __restrict__ flow2, int ld2, int H, int W, int Co,
+                                                          __bf16* __restrict__ out_planes, long long out_pstride, long long out_prows,
+                                                          __bf16* __restrict__ flow_planes, long long flow_pstride, long long flow_prows, int flow_col) {
     __shared__ float2 patch[10 * 14];
     __shared__ __attribute__((aligned(16))) float wsm[98 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,12 +123,29 @@ __global__ __launch_bounds__(512) void flow_encode_kernel(const float* __restric
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int x = tx * 8 + p;
-        if (x < W && cok) out[(img + (size_t)y * W + x) * ldo + c] = fmaxf(acc[p], 0.f);
+        if (x < W && cok) {
+            const float o = fmaxf(acc[p], 0.f);
+            out[(img + (size_t)y * W + x) * ldo + c] = o;
+            if (out_planes) {        // the blocked bf16 planes a split3 consumer reads (st_gemm_desc.split3): 32 lanes = one 64-byte chunk row
+                __bf16 h, m, l;
+                st_split3(o, h, m, l);
+                __bf16* pp = out_planes + ((size_t)(c >> 5) * out_prows + img + (size_t)y * W + x) * 32 + (c & 31);
+                pp[0] = h; pp[out_pstride] = m; pp[2 * out_pstride] = l;
+            }
+        }
     }
     if (flow2 && blockIdx.y == 0 && (wave & 1) == 0 && lane < 8 && tx * 8 + lane < W) {
         const float2 f = patch[(row + 3) * 14 + lane + 3];
         const size_t r = img + (size_t)y * W + tx * 8 + lane;
         flow2[r * ld2] = f.x; flow2[r * ld2 + 1] = f.y;
+        if (flow_planes) {           // channels flow_col, flow_col + 1 (same chunk: flow_col is even) of the GRU input's planes
+            __bf16 h, m, l;
+            __bf16* pp = flow_planes + ((size_t)(flow_col >> 5) * flow_prows + r) * 32 + (flow_col & 31);
+            st_split3(f.x, h, m, l);
+            pp[0] = h; pp[flow_pstride] = m; pp[2 * flow_pstride] = l;
+            st_split3(f.y, h, m, l);
+            pp[1] = h; pp[flow_pstride + 1] = m; pp[2 * flow_pstride + 1] = l;
+        }
     }
 }
 
@@ -134,7 +153,25 @@ extern "C" int st_flow_encode(const float* coords1, const float* w98, const floa
                               int32_t ld2, int32_t B, int32_t H, int32_t W, int32_t Co, void* stream) {
     if (!coords1 || !w98 || !bias || !out || B <= 0 || H <= 0 || W <= 0 || Co <= 0 || (Co & 3) || ((uintptr_t)w98 & 15)) return ST_EINVAL;
     dim3 grid(((H + 3) / 4) * ((W + 7) / 8), (Co + 127) / 128, B);
-    hipLaunchKernelGGL(flow_encode_kernel, grid, dim3(512), 0, (hipStream_t)stream, coords1, w98, bias, out, ldo, flow2, ld2, H, W, Co);
+    hipLaunchKernelGGL(flow_encode_kernel, grid, dim3(512), 0, (hipStream_t)stream, coords1, w98, bias, out, ldo, flow2, ld2, H, W, Co,
+                       (__bf16*)nullptr, 0LL, 0LL, (__bf16*)nullptr, 0LL, 0LL, 0);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// st_flow_encode that ALSO leaves both results as blocked bf16 planes (the operand format of st_gemm_desc.split3): out_planes
+// [3][Co/32][out_prows][32] (planes out_pstride elements apart) and channels flow_col, flow_col + 1 of flow_planes.
+extern "C" int st_flow_encode_split3(const float* coords1, const float* w98, const float* bias, float* out, int32_t ldo, float* flow2,
+                                     int32_t ld2, int32_t B, int32_t H, int32_t W, int32_t Co, void* out_planes, int64_t out_pstride,
+                                     int64_t out_prows, void* flow_planes, int64_t flow_pstride, int64_t flow_prows, int32_t flow_col,
+                                     void* stream) {
+    if (!coords1 || !w98 || !bias || !out || B <= 0 || H <= 0 || W <= 0 || Co <= 0 || (Co & 31) || ((uintptr_t)w98 & 15)) return ST_EINVAL;
+    if (!out_planes || out_pstride <= 0 || out_prows < (int64_t)B * H * W) return ST_EINVAL;
+    if (flow_planes && (!flow2 || flow_pstride <= 0 || flow_prows < (int64_t)B * H * W || flow_col < 0 || (flow_col & 1))) return ST_EINVAL;
+    dim3 grid(((H + 3) / 4) * ((W + 7) / 8), (Co + 127) / 128, B);
+    hipLaunchKernelGGL(flow_encode_kernel, grid, dim3(512), 0, (hipStream_t)stream, coords1, w98, bias, out, ldo, flow2, ld2, H, W, Co,
+                       (__bf16*)out_planes, (long long)out_pstride, (long long)out_prows, (__bf16*)flow_planes, (long long)flow_pstride,
+                       (long long)flow_prows, (int)flow_col);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -70,6 +70,15 @@ __device__ __forceinline__ float gemm_epilogue(const st_gemm_desc& d, int m, int
     return v;
 }
 
+// st_gemm_desc.c_planes: element (m, col) of the plane-carrying output into the three blocked bf16 planes (scalar form: split-K reducer)
+__device__ __forceinline__ void gemm_store_planes(const st_gemm_desc& d, int m, int col, float v) {
+    __bf16 h, mi, lo;
+    st_split3(v, h, mi, lo);
+    const int cc = d.c_plane_col0 + col;
+    __bf16* p = reinterpret_cast<__bf16*>(d.c_planes) + ((size_t)(cc >> 5) * d.c_plane_rows + d.c_plane_row0 + m) * 32 + (cc & 31);
+    p[0] = h; p[d.c_plane_stride] = mi; p[2 * d.c_plane_stride] = lo;
+}
+
 // epilogue + store.  ST_EPI_ZR (fused GRU gates, gru.py:47-49): columns [0, N/2) are z -> C,
 // columns [N/2, N) are r and leave as r*h -> c2 (aux1 = h).
 __device__ __forceinline__ void gemm_store(const st_gemm_desc& d, float* __restrict__ C, int m, int n, float acc, float sc) {
@@ -79,10 +88,16 @@ __device__ __forceinline__ void gemm_store(const st_gemm_desc& d, float* __restr
         if (d.aux0) v += d.aux0[(size_t)m * d.ld_aux0 + n];
         v = st_act(v, d.act);
         if (n < half) C[(size_t)m * d.ldc + n] = v;
-        else d.c2[(size_t)m * d.ldc2 + (n - half)] = v * d.aux1[(size_t)m * d.ld_aux1 + (n - half)];
+        else {
+            const float rh = v * d.aux1[(size_t)m * d.ld_aux1 + (n - half)];
+            if (!d.c_no_f32) d.c2[(size_t)m * d.ldc2 + (n - half)] = rh;
+            if (d.c_planes) gemm_store_planes(d, m, n - half, rh);
+        }
         return;
     }
-    C[(size_t)m * d.ldc + n] = gemm_epilogue(d, m, n, acc, sc);
+    const float o = gemm_epilogue(d, m, n, acc, sc);
+    if (!d.c_no_f32) C[(size_t)m * d.ldc + n] = o;
+    if (d.c_planes) gemm_store_planes(d, m, n, o);
 }
 
 // Epilogue shared by the fp32 and the split-bf16 kernels, in two halves so that the operand loads (bias, the
@@ -111,6 +126,15 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff,
 }
 __device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, (int)soff, 0);
+}
+// st_gemm_desc.c_planes: the lane's value of accumulator row r into the three blocked bf16 planes: lanes li = 0..31 of a sub-tile are
+// the 32 channels of one chunk row, so a wave-instruction writes two 64-byte runs; the plane and the row step are SGPR offsets
+__device__ __forceinline__ void buf_st_planes(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned plane_b) {
+    __bf16 h, mi, lo;
+    st_split3(v, h, mi, lo);
+    __builtin_amdgcn_raw_buffer_store_b16(st_bf16_bits(h), r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b16(st_bf16_bits(mi), r, (int)voff, (int)(soff + plane_b), 0);
+    __builtin_amdgcn_raw_buffer_store_b16(st_bf16_bits(lo), r, (int)voff, (int)(soff + 2u * plane_b), 0);
 }
 // row r of a lane's 16 accumulator registers, relative to the lane's first row
 #define ST_EPI_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
@@ -219,8 +243,14 @@ __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float
         return;
     }
     const bool zr = !LITE && d.epi == ST_EPI_ZR;
-    const __amdgpu_buffer_rsrc_t rc = epi_rsrc(C, ((M - 1) * d.ldc + (zr ? half : d.N)) * 4);
-    const __amdgpu_buffer_rsrc_t rc2 = epi_rsrc(zr ? d.c2 : nullptr, ((M - 1) * d.ldc2 + half) * 4);
+    // c_no_f32: the plane-carrying output (c, or c2 in z|r mode) is not stored as fp32 (zero-record descriptor: the stores are dropped)
+    const __amdgpu_buffer_rsrc_t rc = epi_rsrc((d.c_no_f32 && !zr) ? nullptr : C, ((M - 1) * d.ldc + (zr ? half : d.N)) * 4);
+    const __amdgpu_buffer_rsrc_t rc2 = epi_rsrc((zr && !d.c_no_f32) ? d.c2 : nullptr, ((M - 1) * d.ldc2 + half) * 4);
+    // optional plane copy of the result (st_gemm_desc.c_planes): host-checked M % 32 == 0, c_plane_col0 % 32 == 0, extents < 2 GiB
+    const bool planes = !LITE && d.c_planes != nullptr;
+    const unsigned plane_b = (unsigned)(d.c_plane_stride * 2);
+    const __amdgpu_buffer_rsrc_t rp = epi_rsrc(planes ? reinterpret_cast<const float*>(d.c_planes) : nullptr, 0x7fffffffLL);
+    const long long prow0 = d.c_plane_row0 + (long long)(d.batch > 1 ? blockIdx.z : 0) * d.c_plane_batch_rows;
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int n = n0 + wn * TN * 32 + jn * 32 + li;
@@ -254,19 +284,31 @@ __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float
                     break;
                 default: break;
             }
+            // plane copy: byte offset of (this lane's first row, its channel) inside plane 0; a 32-row sub-tile is wholly inside M
+            unsigned vp = ST_OOB;
+            if (planes) {
+                const int pcol = d.c_plane_col0 + (zr ? n - half : n);
+                if (ncol && (!zr || n >= half) && row0 < d.M) vp = (unsigned)((((long long)(pcol >> 5) * d.c_plane_rows + prow0 + row0) * 32 + (pcol & 31)) * 2);
+            }
             if (zr) {
                 const unsigned vc = (ncol && n < half) ? (unsigned)(row0 * d.ldc + n) * 4u : ST_OOB;
                 const unsigned vc2 = (ncol && n >= half) ? (unsigned)(row0 * d.ldc2 + n - half) * 4u : ST_OOB;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     buf_st(v[r], rc, vc, (unsigned)(ST_EPI_ROW(r) * d.ldc) * 4u);
-                    buf_st(v[r] * e.x1[i][jn][r], rc2, vc2, (unsigned)(ST_EPI_ROW(r) * d.ldc2) * 4u);
+                    const float rh = v[r] * e.x1[i][jn][r];
+                    buf_st(rh, rc2, vc2, (unsigned)(ST_EPI_ROW(r) * d.ldc2) * 4u);
+                    if (planes) buf_st_planes(rh, rp, vp, (unsigned)(ST_EPI_ROW(r) * 64), plane_b);
                 }
             } else {
                 const unsigned vc = ncol ? (unsigned)(row0 * d.ldc + n) * 4u : ST_OOB;
                 if (d.epi == ST_EPI_STORE) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) buf_st(v[r], rc, vc, (unsigned)(ST_EPI_ROW(r) * d.ldc) * 4u);
+                    if (planes) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) buf_st_planes(v[r], rp, vp, (unsigned)(ST_EPI_ROW(r) * 64), plane_b);
+                    }
                     if (CT && d.c_t) {                           // (only the CT instantiations carry this code)
                         // transposed copy: the lane's 16 values are 4 runs of 4 consecutive rows of column n -> 4 x 16-byte stores
                         // into row n of c_t (M % 4 == 0: a run is inside the matrix or wholly outside)
@@ -289,6 +331,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float
                         else if (!LITE && d.epi == ST_EPI_GRU) o = (1.0f - x1) * e.x2[i][jn][r] + x1 * v[r];
                         else if (d.epi == ST_EPI_AXPY) o = fmaf(e.sc, v[r], x1);
                         buf_st(o, rc, vc, (unsigned)(ST_EPI_ROW(r) * d.ldc) * 4u);
+                        if (planes) buf_st_planes(o, rp, vp, (unsigned)(ST_EPI_ROW(r) * 64), plane_b);
                     }
                 }
             }
@@ -1764,8 +1807,24 @@ static int launch_rowstream(const st_gemm_desc& d, int max_cps, hipStream_t s) {
     return ST_OK;
 }
 
+// st_gemm_desc.c_planes: what every kernel that can emit planes needs checked
+static bool c_planes_ok(const st_gemm_desc& d) {
+    if (d.reserved4 != 0) return false;
+    if (!d.c_planes) return d.c_no_f32 == 0;
+    const int batch = d.batch > 0 ? d.batch : 1;
+    const int ncols = d.epi == ST_EPI_ZR ? d.N / 2 : d.N;
+    if ((d.M & 31) || (d.c_plane_col0 & 31) || d.c_plane_col0 < 0 || d.c_plane_row0 < 0 || d.c_plane_stride <= 0 || (d.c_plane_stride & 7) || d.c_plane_rows <= 0 ||
+        ((uintptr_t)d.c_planes & 15) || d.c_t)
+        return false;
+    const int64_t last_row = d.c_plane_row0 + (int64_t)(batch - 1) * d.c_plane_batch_rows + d.M;
+    if (last_row > d.c_plane_rows) return false;
+    const int64_t chunks = (d.c_plane_col0 + ncols + 31) / 32;
+    return 2 * (2 * d.c_plane_stride + chunks * d.c_plane_rows * 32) < ((int64_t)1 << 31);
+}
+
 static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream);
 static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
+    if (!c_planes_ok(*desc)) return ST_EINVAL;
     if (desc->split3) return conv_gemm_split3_launch(desc, stream);
     st_gemm_desc d = *desc;
     if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
@@ -1798,7 +1857,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         if (ab >= (int64_t)ST_OOB || ((int64_t)d.M + 256) * ldmax * 4 >= lim) {
             // Larger than the 32-bit offsets reach (whole-batch PatchEmbed maps at B >= 4, ...): run the rows in chunks.
             // A chunk is a whole number of images (convs) and of aux0 mapping periods, so every operand just shifts its base.
-            if ((d.batch > 1) || d.split_k > 1 || d.c_t) return ST_EINVAL;
+            if ((d.batch > 1) || d.split_k > 1 || d.c_t || d.c_planes) return ST_EINVAL;
             const int64_t div = d.aux0_row_div > 1 ? d.aux0_row_div : 1, mod = d.aux0_row_mod > 0 ? d.aux0_row_mod : 1;
             int64_t unit = hw;                                           // rows per indivisible unit
             {
@@ -1842,13 +1901,13 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
                          (d.ldw % 4 == 0) && (d.Cin % 4 == 0) &&
                          (d.batch_stride_a % 4 == 0) && (d.batch_stride_w % 4 == 0);
     const int batch = d.batch > 0 ? d.batch : 1;
-    if (d.M <= 8 && d.kh == 1 && d.kw == 1 && aligned && batch == 1 && d.epi == ST_EPI_STORE && !d.aux0 && d.H * d.W == d.M && !d.a2 && !d.c_t) {
+    if (d.M <= 8 && d.kh == 1 && d.kw == 1 && aligned && batch == 1 && d.epi == ST_EPI_STORE && !d.aux0 && d.H * d.W == d.M && !d.a2 && !d.c_t && !d.c_planes) {
         g_last_plan[0] = 0; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 0;
         hipLaunchKernelGGL(skinny_gemm_kernel<8>, dim3((d.N * 64 + 255) / 256), dim3(256), 0, s, d);
         ST_CHECK_LAUNCH();
         return ST_OK;
     }
-    if (d.N <= 4 && aligned && batch == 1 && d.epi != ST_EPI_ZR && d.M >= 1024 && d.tile_cfg == 0 && d.split_k <= 1 && !d.a2 && !d.c_t) {
+    if (d.N <= 4 && aligned && batch == 1 && d.epi != ST_EPI_ZR && d.M >= 1024 && d.tile_cfg == 0 && d.split_k <= 1 && !d.a2 && !d.c_t && !d.c_planes) {
         g_last_plan[0] = 1; g_last_plan[1] = 0; g_last_plan[2] = 1; g_last_plan[3] = 0;
         if (d.N <= 2 && d.Cin == 256 && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 && d.dh <= 1 && d.dw <= 1 &&
             d.Ho == d.H && d.Wo == d.W) {
@@ -1867,7 +1926,7 @@ static int conv_gemm_launch(const st_gemm_desc* desc, void* stream) {
         const bool plain = d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && (int64_t)d.H * d.W == d.M;
         const bool map_ok = (d.aux0_row_div <= 1 && (d.aux0_row_mod <= 0 || d.aux0_row_mod % 32 == 0)) ||
                             (d.aux0_row_div == 8 && d.aux0_row_mod <= 0) || !d.aux0;
-        const bool rs_ok = plain && aligned && batch == 1 && !d.a2 && !d.c_t && d.split_k <= 1 && (d.K == 64 || d.K == 128) &&
+        const bool rs_ok = plain && aligned && batch == 1 && !d.a2 && !d.c_t && !d.c_planes && d.split_k <= 1 && (d.K == 64 || d.K == 128) &&
                            d.epi != ST_EPI_ZR && d.epi != ST_EPI_GRU && map_ok;
         // measured on MI355X, in the pipeline and stand-alone (tools/rowstream_bench.py): ahead of the LDS-DMA kernel for K = 64,
         // for M >= 262144 and for N >= 384; behind it by ~2 us per launch at M <= 65536, N = 128 (one block per wave: all
@@ -1960,8 +2019,9 @@ static int launch_split3(const st_gemm_desc& d, hipStream_t s) {
     return ST_OK;
 }
 
-static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
-    st_gemm_desc d = *desc;
+// checks + buffer extents of a split3 descriptor (shared by st_conv_gemm and st_conv_gemm_pair)
+static int split3_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
+    d = *desc;
     if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
     if (d.kh <= 0 || d.kw <= 0 || d.K != d.kh * d.kw * d.Cin || d.Cin % 32) return ST_EINVAL;
     if (d.Ho <= 0 || d.Wo <= 0 || d.M % (d.Ho * d.Wo)) return ST_EINVAL;
@@ -1969,6 +2029,7 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
     if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0 || d.reserved3 != 0 || d.c_t || d.a_ln) return ST_EINVAL;
+    if (!c_planes_ok(d)) return ST_EINVAL;
     if (d.a_plane_stride <= 0 || d.w_plane_stride <= 0 || d.a_rows <= 0 || d.w_rows < d.N) return ST_EINVAL;
     if (((uintptr_t)d.a & 15) || ((uintptr_t)d.w & 15) || (d.a_plane_stride & 7) || (d.w_plane_stride & 7) || (d.batch_stride_a & 7) ||
         (d.batch_stride_w & 7))
@@ -1989,9 +2050,20 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
     if (d.c2 && d.ldc2 > ldmax) ldmax = d.ldc2;
     if (((int64_t)d.M + 256) * ldmax * 4 >= ((int64_t)1 << 31)) return ST_EINVAL;
     d.a_bytes = (uint32_t)ab; d.w_bytes = (uint32_t)wb;
+    return ST_OK;
+}
+
+static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
+    st_gemm_desc d;
+    {
+        const int rc = split3_prepare(desc, d);
+        if (rc) return rc;
+    }
     const int batch = d.batch > 0 ? d.batch : 1;
     int cfg = d.tile_cfg;
-    if (cfg == 0) cfg = 31;
+    // measured (tools/split3_probe.py, profiles/r6_split3_probe.json): 128x64 tiles on a 4-stage ring win when they still give every CU a
+    // workgroup (N = 256 at M = 8 192: 41.8 vs 44.2 us), 64x64 tiles (two workgroups per CU) otherwise; 128x128 never
+    if (cfg == 0) cfg = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * batch >= 256 ? 32 : 34;
     static const int bms[7] = {0, 128, 128, 64, 64, 128, 64}, bns[7] = {0, 128, 64, 128, 64, 64, 64};
     if (cfg < 31 || cfg > 36) return ST_EINVAL;
     const long tiles = (long)((d.M + bms[cfg - 30] - 1) / bms[cfg - 30]) * ((d.N + bns[cfg - 30] - 1) / bns[cfg - 30]) * batch;
@@ -2042,6 +2114,7 @@ extern "C" int st_split3_pack(const float* x, void* planes, int64_t rows, int32_
 // Checks + buffer extents of a descriptor that must run on the plain (non-persistent, unsplit) 64x64 LDS-DMA kernel.
 static int pair_member_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
     d = *desc;
+    if (!c_planes_ok(d)) return ST_EINVAL;
     if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return ST_EINVAL;
     if (d.kh <= 0 || d.kw <= 0 || d.K != d.kh * d.kw * d.Cin || d.K < 128 || d.Cin % 32) return ST_EINVAL;
     if (d.Ho <= 0 || d.Wo <= 0 || d.M % (d.Ho * d.Wo)) return ST_EINVAL;
@@ -2069,6 +2142,30 @@ static int pair_member_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
 extern "C" int st_conv_gemm_pair(const st_gemm_desc* desc0, const st_gemm_desc* desc1, void* stream) {
     if (!desc0 || !desc1) return ST_EINVAL;
     st_gemm_pair_args g;
+    if (desc0->split3 || desc1->split3) {            // both split3: 64x64 tiles, no split-K, one launch of 8-wave workgroups
+        if (!desc0->split3 || !desc1->split3) return ST_EINVAL;
+        for (int i = 0; i < 2; ++i) {
+            const st_gemm_desc* di = i ? desc1 : desc0;
+            if (di->batch > 1 || di->split_k > 1 || (di->tile_cfg != 0 && di->tile_cfg != 34)) return ST_EINVAL;
+            const int rc = split3_prepare(di, g.d[i]);
+            if (rc) return rc;
+            g.d[i].split_k = 1; g.d[i].batch = 1;
+        }
+        auto tiles3 = [](const st_gemm_desc& d) { return ((d.M + 63) / 64) * ((d.N + 63) / 64); };
+        g.tiles0 = tiles3(g.d[0]);
+        const int total3 = g.tiles0 + tiles3(g.d[1]);
+        st_gemm_observer_fn obs3 = g_observer;
+        g_last_plan[0] = 7; g_last_plan[1] = 34; g_last_plan[2] = 1; g_last_plan[3] = 2;
+        if (obs3) { obs3(desc0, stream, 0, g_observer_user); obs3(desc0, stream, 1, g_observer_user); obs3(desc1, stream, 0, g_observer_user); }
+        g_last_plan[3] = 3;
+        auto k3 = conv_gemm_split3_pair_kernel<2, 2, 1, 1, 3>;
+        const size_t lds3 = (size_t)3 * 3 * 128 * 64;
+        (void)hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        hipLaunchKernelGGL(k3, dim3(total3), dim3(512), lds3, (hipStream_t)stream, g);
+        if (obs3) obs3(desc1, stream, 1, g_observer_user);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     int rc = pair_member_prepare(desc0, g.d[0]);
     if (rc) return rc;
     rc = pair_member_prepare(desc1, g.d[1]);

@@ -21,24 +21,6 @@
 // gma.py:102-115 (aggregate), encoder.py:359-369 (all-pairs correlation).
 #pragma once
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
-// x -> (hi, mid, lo), x == hi + mid + lo exactly for every finite x with |x| >= 2^-110 (below that lo leaves bf16's
-// subnormal range).  +-inf / NaN stay in hi alone (mid = lo = 0): inf - inf would otherwise make the residual NaN and turn
-// inf . finite into NaN; an x that only bf16 rounding pushes to inf keeps the largest finite bf16 as hi.
-__device__ __forceinline__ void st_split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
-    hi = (__bf16)x;
-    float hf = (float)hi;
-    if (__builtin_isinf(hf) || hf != hf) {
-        if (__builtin_isinf(x) || x != x) { mid = (__bf16)0.f; lo = (__bf16)0.f; return; }
-        hf = copysignf(3.3895313892515355e38f, x);          // 0x7F7F0000: largest finite bf16
-        hi = (__bf16)hf;
-    }
-    const float r1 = x - hf;
-    mid = (__bf16)r1;
-    lo = (__bf16)(r1 - (float)mid);
-}
 
 // fp32 [rows, ldx] (C columns, C % 32 == 0) -> three blocked planes.  One thread = 8 channels of one row.
 __global__ __launch_bounds__(256) void split3_pack_kernel(const float* __restrict__ x, __bf16* __restrict__ planes, long long rows, int C,
@@ -300,4 +282,11 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
 template <int WM, int WN, int TM, int TN, int STAGES, int DIAG = 0>
 __global__ __launch_bounds__(512) void conv_gemm_split3_kernel(const st_gemm_desc d) {
     conv_gemm_split3_body<WM, WN, TM, TN, STAGES, DIAG>(d, (int)blockIdx.x);
+}
+
+// two independent split3 contractions in one launch (st_conv_gemm_pair with split3 descriptors): workgroups [0, tiles0) run d[0], the rest d[1]
+template <int WM, int WN, int TM, int TN, int STAGES>
+__global__ __launch_bounds__(512) void conv_gemm_split3_pair_kernel(const st_gemm_pair_args g) {
+    const bool second = (int)blockIdx.x >= g.tiles0;             // workgroup-uniform
+    conv_gemm_split3_body<WM, WN, TM, TN, STAGES, 0>(second ? g.d[1] : g.d[0], second ? (int)blockIdx.x - g.tiles0 : (int)blockIdx.x);
 }

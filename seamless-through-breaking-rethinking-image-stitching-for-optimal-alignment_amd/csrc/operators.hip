@@ -168,4 +168,74 @@ int st_sepconv_gru(float* hxA, float* hxB, int32_t ld, float* zbuf, const float*
     return ST_OK;
 }
 
+// ---- the same two operators on exact-split operands (st_gemm_desc.split3, csrc/gemm_split3.h) ----------------------------------
+// Plane tensors: three blocked bf16 planes [C / 32][rows][32], `pstride` ELEMENTS apart, `prows` = rows per chunk.
+
+// st_gma_aggregate with attn and v^T as planes.  attn_planes: [3][N/32][B*N][32] (st_split3_pack of the attention matrix, once per pass);
+// vT_planes: scratch [3][N/32][B*128][32], written by the v projection's epilogue; out (mf + gamma attn v) leaves as fp32 AND as columns
+// out_col .. out_col+127 of out_planes (the GRU input's planes).  Matches gma.py:102-115.
+int st_gma_aggregate_split3(const void* attn_planes, int64_t attn_pstride, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma,
+                            float* vT, void* vT_planes, int64_t vT_pstride, float* out, int32_t ld_out, void* out_planes, int64_t out_pstride,
+                            int64_t out_prows, int32_t out_col, int32_t B, int32_t N, void* workspace, int64_t workspace_floats, void* stream) {
+    if (!attn_planes || !mf || !w_v || !gamma || !vT || !vT_planes || !out || !out_planes || B <= 0 || N <= 0 || (N & 31)) return ST_EINVAL;
+    {
+        // vT[b] = Wv . mf[b]^T  (K = 128: the exact fp32 kernel), emitted as planes: rows b*128 .. b*128+127 of every pixel chunk
+        Gemm g(w_v, 128, mf, ld_mf, vT, N, 128, N, 128);
+        g.batched(B, 0, (int64_t)N * ld_mf, (int64_t)128 * N);
+        g.d.c_planes = vT_planes; g.d.c_plane_stride = vT_pstride; g.d.c_plane_rows = (int64_t)B * 128; g.d.c_plane_batch_rows = 128;
+        ST_TRY(g.run(stream));
+    }
+    {
+        Gemm g((const float*)attn_planes, N, (const float*)vT_planes, N, out, ld_out, N, 128, N);
+        g.epi(ST_EPI_AXPY, mf, ld_mf).scale(gamma).batched(B, (int64_t)N * 32, (int64_t)128 * 32, (int64_t)N * ld_out);
+        g.d.batch_stride_aux1 = (int64_t)N * ld_mf;
+        g.d.split3 = 1;
+        g.d.a_plane_stride = attn_pstride; g.d.a_rows = (int64_t)B * N;
+        g.d.w_plane_stride = vT_pstride; g.d.w_rows = (int64_t)B * 128;
+        g.d.c_planes = out_planes; g.d.c_plane_stride = out_pstride; g.d.c_plane_rows = out_prows; g.d.c_plane_col0 = out_col;
+        g.d.c_plane_batch_rows = N;
+        if (B == 1) g.work(workspace, workspace_floats);
+        ST_TRY(g.run(stream));
+    }
+    return ST_OK;
+}
+
+// st_sepconv_gru on planes.  hxA_planes / hxB_planes: [3][ld/32][prows][32] images of hxA = [h | x] and hxB = [r*h | unused] (same strides);
+// the kernels read ONLY the planes as contraction operands, the fp32 hxA[:, :128] (h) stays the epilogue operand and receives the new
+// state; r*h exists only as planes.  Weights: planes of w_zr* [256, 5*ld] / w_q* [128, 5*ld] (st_split3_pack at load time), all
+// `w_pstride_zr` / `w_pstride_q` apart.  Matches gru.py:44-59.
+int st_sepconv_gru_split3(float* hxA, int32_t ld, void* hxA_planes, void* hxB_planes, int64_t pstride, int64_t prows, float* zbuf,
+                          const float* tab1, const float* tab2, int32_t ld_tab, const void* w_zr1, const void* w_q1, const void* w_zr2,
+                          const void* w_q2, int64_t w_pstride_zr, int64_t w_pstride_q, int32_t B, int32_t H, int32_t W, void* workspace,
+                          int64_t workspace_floats, void* stream) {
+    if (!hxA || !hxA_planes || !hxB_planes || !zbuf || !tab1 || !tab2 || !w_zr1 || !w_q1 || !w_zr2 || !w_q2 || ld < 128 || (ld & 31) ||
+        ld_tab < 384 || B <= 0 || H <= 0 || W <= 0 || prows < (int64_t)B * H * W)
+        return ST_EINVAL;
+    const float* tabs[2] = {tab1, tab2};
+    const void* wzr[2] = {w_zr1, w_zr2};
+    const void* wq[2] = {w_q1, w_q2};
+    for (int p = 0; p < 2; ++p) {
+        const int kh = p ? 5 : 1, kw = p ? 1 : 5, ph = p ? 2 : 0, pw = p ? 0 : 2;
+        {
+            // z | r: z -> zbuf (fp32, the blend's operand), r*h -> columns 0..127 of hxB's planes only
+            Gemm g((const float*)hxA_planes, ld, (const float*)wzr[p], 5 * ld, zbuf, 128, 0, 256, ld);
+            g.conv(B, H, W, kh, kw, 1, 1, ph, pw).aux0(tabs[p], ld_tab).act(ST_ACT_SIGMOID).epi(ST_EPI_ZR, hxA, ld).out2(hxA /* unused: c_no_f32 */, ld)
+                .work(workspace, workspace_floats);
+            g.d.split3 = 1; g.d.a_plane_stride = pstride; g.d.a_rows = prows; g.d.w_plane_stride = w_pstride_zr; g.d.w_rows = 256;
+            g.d.c_planes = hxB_planes; g.d.c_plane_stride = pstride; g.d.c_plane_rows = prows; g.d.c_no_f32 = 1;
+            ST_TRY(g.run(stream));
+        }
+        {
+            // q on [r*h (hxB planes) | x (hxA planes)], GRU blend with z and the fp32 h; new h -> hxA fp32 AND columns 0..127 of hxA's planes
+            Gemm g((const float*)hxA_planes, ld, (const float*)wq[p], 5 * ld, hxA, ld, 0, 128, ld);
+            g.a2((const float*)hxB_planes, 128).conv(B, H, W, kh, kw, 1, 1, ph, pw).aux0(tabs[p] + 256, ld_tab).act(ST_ACT_TANH)
+                .epi(ST_EPI_GRU, zbuf, 128, hxA, ld).work(workspace, workspace_floats);
+            g.d.split3 = 1; g.d.a_plane_stride = pstride; g.d.a_rows = prows; g.d.w_plane_stride = w_pstride_q; g.d.w_rows = 128;
+            g.d.c_planes = hxA_planes; g.d.c_plane_stride = pstride; g.d.c_plane_rows = prows;
+            ST_TRY(g.run(stream));
+        }
+    }
+    return ST_OK;
+}
+
 }  // extern "C"

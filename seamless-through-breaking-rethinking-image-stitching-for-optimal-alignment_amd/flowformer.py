@@ -40,7 +40,13 @@ FUSE_CHAIN = os.environ.get("ST_FUSE_CHAIN", "1") != "0"        # the latent lay
 # into the forward's hipGraph as a parallel branch.  Same kernels, same operands: bit-identical.  Measured in round 5 (section 5 of DESIGN.md).
 FORK = os.environ.get("ST_FORK", "0") == "1"
 FORK_ENC = os.environ.get("ST_FORK_ENC", "0") == "1"           # experiment: flow_encode of an iteration on a side stream beside cost lookup + token chain (which fill half the CUs)
+# The decoder's long-K contractions (SepConvGRU, motion-encoder 3x3 convs, GMA aggregate, flow / mask head conv1: ~5.3 of the 12 ms of a pair)
+# on the bf16 matrix cores with EXACTLY split operands (csrc/gemm_split3.h: x = hi + mid + lo in three bf16, six products, fp32 accumulate --
+# error against fp64 0.83x the fp32 MFMA chain's, 1.5-1.76x its speed, profiles/r6_split3_probe.json).  Every operand travels as blocked
+# bf16 planes written by the epilogue of the kernel that produced it; ST_SPLIT3=0 = the fp32-MFMA kernels of rounds 1-5 (A/B).
+SPLIT3 = os.environ.get("ST_SPLIT3", "1") != "0"
 FUSE_PE = os.environ.get("ST_FUSE_PE", "1") != "0"              # PatchEmbed c0 + c2 per cost map in one launch (csrc/patchembed.hip; the library reads the same switch)
+assert not (SPLIT3 and FORK_ENC), "ST_FORK_ENC is an fp32-path experiment"
 _SIDE = {}
 
 
@@ -223,6 +229,10 @@ class FlowFormer(ParamTree):
             dec["q" + sfx] = parts["q"][0]
             dec["inp" + sfx] = (torch.cat([parts[g][1] for g in ("z", "r", "q")], 0).contiguous(),
                                 torch.cat([parts[g][2] for g in ("z", "r", "q")], 0).contiguous())
+        if SPLIT3:
+            # exact three-way bf16 split of the weights of the split3 launches, once (K ordered (tap, channel) as in the fp32 matrices)
+            dec["s3"] = {k: ops.split3_pack(dec[k] if torch.is_tensor(dec[k]) else dec[k][0])
+                         for k in ("zr1", "q1", "zr2", "q2", "convc2", "convf2", "conv", "fh1", "m0")}
         pk["dec"] = dec
         self._pk = pk
         return pk
@@ -509,9 +519,17 @@ class FlowFormer(ParamTree):
     def _update_state(self, R, B, N, dev):
         """work buffers of the refinement loop.  hxA = [h | motion(126)+flow(2) | motion_global], hxB = [r*h | unused] (same stride);
         corr = [cost_forward 81 | 3 zero | cost_global 64 | 12 zero]."""
-        return dict(hxA=_new(R, 384, dev), hxB=_new(R, 384, dev), corr=_new(R, 160, dev, zero=True),
-                    cor1=_new(R, 256, dev), corflo=_new(R, 256, dev), flo1=_new(R, 128, dev),
-                    vT=torch.empty((B, 128, N), device=dev), zbuf=_new(R, 128, dev), fh=_new(R, 256, dev))
+        S = dict(hxA=_new(R, 384, dev), hxB=_new(R, 384, dev), corr=_new(R, 160, dev, zero=True),
+                 cor1=_new(R, 256, dev), corflo=_new(R, 256, dev), flo1=_new(R, 128, dev),
+                 vT=torch.empty((B, 128, N), device=dev), zbuf=_new(R, 128, dev), fh=_new(R, 256, dev))
+        S["s3"] = SPLIT3 and N % 32 == 0          # (plane rows are whole 32-row tiles; other map sizes keep the fp32 kernels)
+        if S["s3"]:
+            # plane images (ops.Planes) of the tensors the split3 contractions read; hxB's image only ever holds r*h (columns 0..127) but
+            # shares hxA's strides (second A source of the q convs).  Every channel that is read is written first in each iteration:
+            # hxA 0..127 by the q convs / proj_net, 128..253 by `conv`, 254..255 by flow_encode, 256..383 by the aggregate.
+            S.update(hxA_p=ops.Planes(R, 384, dev), hxB_p=ops.Planes(R, 384, dev), cor1_p=ops.Planes(R, 256, dev), flo1_p=ops.Planes(R, 128, dev),
+                     corflo_p=ops.Planes(R, 256, dev), vT_p=ops.Planes(B * 128, N, dev))
+        return S
 
     def _update_block(self, S, coords1, attn, gru_tab, B, H1, W1, enc_done=None):
         """GMAUpdateBlock.forward (gru.py:322-334) without the mask head: BasicMotionEncoder (gru.py:246-254), GMA
@@ -521,6 +539,24 @@ class FlowFormer(ParamTree):
         N = H1 * W1
         hxA, hxB, corr = S["hxA"], S["hxB"], S["corr"]
         g3 = (B, H1, W1, 3, 3, 1, 1, 1, 1)
+        if S["s3"]:
+            W3 = D["s3"]
+            hxA_p = S["hxA_p"]
+            if torch.is_tensor(attn):      # a caller that built the attention matrix itself (tests): its planes, here
+                attn = ops.split3_pack(attn.view(B * N, N))
+            # convc1 (K = 160) stays on the fp32 kernel and emits cor1's planes; flow_encode emits flo1's and the flow's two channels
+            ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu", out_planes=S["cor1_p"])
+            ops.flow_encode_split3(coords1, D["convf1"][0], D["convf1"][1], S["flo1"], hxA[:, 254:256], B, H1, W1, S["flo1_p"], (hxA_p, 254))
+            ops.conv_gemm_pair((S["cor1_p"], W3["convc2"], S["corflo"][:, :192],
+                                dict(geom=g3, bias=D["convc2"][1], act="relu", out_planes=S["corflo_p"].cols(0, 192), no_f32=True)),
+                               (S["flo1_p"], W3["convf2"], S["corflo"][:, 192:],
+                                dict(geom=g3, bias=D["convf2"][1], act="relu", out_planes=S["corflo_p"].cols(192, 256), no_f32=True)))
+            ops.conv_gemm(S["corflo_p"], W3["conv"], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu", out_planes=hxA_p.cols(128, 256))
+            ops.gma_aggregate_split3(attn, hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], S["vT_p"], hxA[:, 256:], hxA_p.cols(256, 384), B, N)
+            ops.sepconv_gru_split3(hxA, hxA_p, S["hxB_p"], S["zbuf"], gru_tab["1"], gru_tab["2"], W3["zr1"], W3["q1"], W3["zr2"], W3["q2"], B, H1, W1)
+            ops.conv_gemm(hxA_p.cols(0, 128), W3["fh1"], S["fh"], geom=g3, bias=D["fh1"][1], act="relu")
+            ops.conv_gemm(S["fh"], D["fh2"][0], coords1, geom=g3, bias=D["fh2"][1], epi="add", aux1=coords1)
+            return
         ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu")
         if enc_done is not None:
             torch.cuda.current_stream().wait_event(enc_done)         # ST_FORK_ENC: already enqueued on the side stream by _decoder
@@ -545,7 +581,10 @@ class FlowFormer(ParamTree):
     def _mask_head(self, S, B, H1, W1):
         """mask = .25 * conv1x1(relu(conv3x3(net))) (gru.py:315-318,333) -> rows [R, 576]."""
         D = self._pk["dec"]
-        ops.conv_gemm(S["hxA"][:, :128], D["m0"][0], S["fh"], geom=(B, H1, W1, 3, 3, 1, 1, 1, 1), bias=D["m0"][1], act="relu")
+        if S["s3"]:
+            ops.conv_gemm(S["hxA_p"].cols(0, 128), D["s3"]["m0"], S["fh"], geom=(B, H1, W1, 3, 3, 1, 1, 1, 1), bias=D["m0"][1], act="relu")
+        else:
+            ops.conv_gemm(S["hxA"][:, :128], D["m0"][0], S["fh"], geom=(B, H1, W1, 3, 3, 1, 1, 1, 1), bias=D["m0"][1], act="relu")
         mask = _new(S["hxA"].shape[0], 576, S["hxA"].device)
         ops.conv_gemm(S["fh"], D["m2"][0], mask, bias=D["m2"][1], alpha=0.25)
         return mask
@@ -559,12 +598,15 @@ class FlowFormer(ParamTree):
         R = B * N
         S = self._update_state(R, B, N, dev)
         inp = _new(R, 128, dev)
-        ops.conv_gemm(ctx, D["proj_net"][0], S["hxA"][:, :128], bias=D["proj_net"][1], act="tanh")
+        ops.conv_gemm(ctx, D["proj_net"][0], S["hxA"][:, :128], bias=D["proj_net"][1], act="tanh",
+                      out_planes=S["hxA_p"].cols(0, 128) if S["s3"] else None)
         ops.conv_gemm(ctx, D["proj_inp"][0], inp, bias=D["proj_inp"][1], act="relu")
         gru_tab = self._gru_tables(inp, B, H1, W1)
         qk = _new(R, 256, dev)
         attn = torch.empty((B, N, N), device=dev)
         ops.gma_attention(inp, D["qk"], qk, attn, B, N)
+        if S["s3"]:                # the attention matrix is read 12 times as a contraction operand: its planes, once per pass
+            attn = ops.split3_pack(attn.view(B * N, N))
         return dict(S=S, inp=inp, gru_tab=gru_tab, attn=attn, qk=qk)
 
     def _decoder(self, mem, mem_short, ctx, cost_maps, B, H1, W1, iters, trace=None, pre=None):

@@ -41,6 +41,56 @@ def _ld(t):
     return t.stride(0)
 
 
+class _Stub:
+    """shape-only stand-in for an operand that conv_gemm addresses through Planes"""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+    def dim(self):
+        return len(self.shape)
+
+    def stride(self, i):
+        return self.shape[1] if i == 0 else 1
+
+    def data_ptr(self):
+        return 0
+
+
+class Planes:
+    """Three blocked bf16 planes (hi, mid, lo; x == hi + mid + lo exactly) of a channels-last fp32 tensor [rows, C], C % 32 == 0: the operand
+    format of the exact-split contraction (``st_gemm_desc.split3``, csrc/gemm_split3.h).  Storage ``t`` = [3, C / 32, rows, 32] bf16.
+    ``cols(c0, c1)`` is a column slice (whole 32-channel chunks) sharing the storage -- concatenation stays a column offset."""
+
+    def __init__(self, rows, C, dev, t=None, c0=0, ncols=None):
+        assert C % 32 == 0, C
+        self.rows, self.C = rows, C
+        self.t = t if t is not None else torch.empty((3, C // 32, rows, 32), device=dev, dtype=torch.bfloat16)
+        self.c0, self.ncols = c0, (C if ncols is None else ncols)
+
+    def cols(self, c0, c1):
+        assert c0 % 32 == 0 and 0 <= c0 < c1 <= self.ncols, (c0, c1, self.ncols)
+        return Planes(self.rows, self.C, None, t=self.t, c0=self.c0 + c0, ncols=c1 - c0)
+
+    @property
+    def pstride(self):
+        return self.t.stride(0)
+
+    def ptr(self):
+        """address of (plane 0, first chunk of this slice)"""
+        return self.t.data_ptr() + (self.c0 // 32) * self.rows * 64
+
+
+def split3_pack(x, out=None, chunk_rows=None):
+    """fp32 rows [rows, C] (row stride >= C) -> Planes (st_split3_pack): weights at pack time, activations no split3-emitting kernel produced."""
+    rows, Cc = x.shape
+    if out is None:
+        out = Planes(chunk_rows or rows, Cc, x.device)
+    assert out.ncols == Cc and out.rows >= rows
+    check(lib.st_split3_pack(_p(x), C.c_void_p(out.ptr()), rows, Cc, _ld(x), out.pstride, out.rows, _stream()), "st_split3_pack")
+    return out
+
+
 _WS = {}
 _WS_OVERRIDE = []
 
@@ -91,7 +141,7 @@ class workspace_scope:
 
 def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=None, row_div=0, row_mod=0,
               epi="store", aux1=None, aux2=None, scale_ptr=None, batch=1, bsa=0, bsw=0, bsc=0, bsx1=0, dil=(1, 1), M=None, tile=0, split_k=0, out2=None,
-              ln_eps=None, a2=None, a2_channels=0, _desc_only=False):
+              ln_eps=None, a2=None, a2_channels=0, _desc_only=False, out_planes=None, plane_row0=0, plane_batch_rows=0, no_f32=False, N=None):
     """out[M,N] = epilogue(alpha * conv(x) @ w^T + bias).
 
     _desc_only=True returns the filled descriptor without launching (``conv_gemm_pair``).
@@ -101,8 +151,24 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     the kernel before the product (row-streaming kernel only: plain matrix, K = 64 / 128).
 
     x: 2-D view [rows, Cin] of a channels-last activation; geom=(B,H,W,kh,kw,sh,sw,ph,pw) or None (1x1).
-    w: [N, kh*kw*Cin] view.  out/aux*: 2-D views (column slices of wider buffers are fine)."""
+    w: [N, kh*kw*Cin] view.  out/aux*: 2-D views (column slices of wider buffers are fine).
+
+    Exact-split operands (``st_gemm_desc.split3``): x, w (and a2) given as ``Planes`` -- x a column slice of the activation's planes, w the
+    ``split3_pack`` image of the [N, K] weight matrix.  out_planes (a ``Planes`` column slice, any kernel of the family): the result also
+    leaves as planes, rows plane_row0 + batch * plane_batch_rows + m; no_f32 skips the fp32 store of that output."""
     d = GemmDesc()
+    split3 = isinstance(x, Planes)
+    if split3:
+        assert isinstance(w, Planes) and (a2 is None or isinstance(a2, Planes))
+        xp, wp, a2p = x, w, a2
+        Cin = xp.ncols
+        d.split3 = 1
+        d.a_plane_stride, d.a_rows = xp.pstride, xp.rows
+        d.w_plane_stride, d.w_rows = wp.pstride, wp.rows
+        # stand-ins with the shapes the fp32 path reads below (pointers are replaced afterwards)
+        x = _Stub((xp.rows, Cin))
+        w = _Stub((wp.rows, wp.ncols))
+        a2 = None
     Cin = x.shape[1]
     if geom is None:
         rows = x.shape[0] if M is None else M
@@ -120,7 +186,7 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     d.aux1 = aux1.data_ptr() if aux1 is not None else None
     d.aux2 = aux2.data_ptr() if aux2 is not None else None
     d.scale_ptr = scale_ptr.data_ptr() if scale_ptr is not None else None
-    d.M, d.N, d.K = B * Ho * Wo, w.shape[0], kh * kw * Cin
+    d.M, d.N, d.K = B * Ho * Wo, (w.shape[0] if N is None else N), kh * kw * Cin          # (N: batched W planes hold every batch's rows)
     assert w.shape[1] == d.K, (tuple(w.shape), d.K)
     d.H, d.W, d.Cin, d.ldx = H, W, Cin, _ld(x)
     d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.Ho, d.Wo = kh, kw, sh, sw, ph, pw, Ho, Wo
@@ -140,12 +206,22 @@ def conv_gemm(x, w, out, *, geom=None, bias=None, act="none", alpha=1.0, aux0=No
     if a2 is not None:
         assert a2.shape == x.shape and _ld(a2) == _ld(x), "second A source: same geometry and row stride as x"
         d.a2, d.a2_channels = a2.data_ptr(), int(a2_channels)
+    if split3:
+        d.a, d.w = xp.ptr(), wp.ptr()
+        d.ldx, d.ldw = Cin, d.K
+        if a2p is not None:
+            assert a2p.pstride == xp.pstride and a2p.rows == xp.rows, "second A source: planes of the same geometry"
+            d.a2, d.a2_channels = a2p.ptr(), int(a2_channels)
+    if out_planes is not None:
+        d.c_planes, d.c_plane_stride, d.c_plane_rows = out_planes.t.data_ptr(), out_planes.pstride, out_planes.rows
+        d.c_plane_col0, d.c_plane_row0, d.c_plane_batch_rows = out_planes.c0, int(plane_row0), int(plane_batch_rows)
+        d.c_no_f32 = 1 if no_f32 else 0
     if out2 is not None:
         d.c2, d.ldc2 = out2.data_ptr(), _ld(out2)
     if _desc_only:
         return d
     if batch <= 1 and split_k != 1:
-        ws = _workspace(x.device)
+        ws = _workspace(out.device)
         d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     check(lib.st_conv_gemm(C.byref(d), _stream()), "st_conv_gemm")
     return out
@@ -329,6 +405,16 @@ def flow_encode(coords1, w98, bias, out, flow2, B, H, W):
     return out
 
 
+def flow_encode_split3(coords1, w98, bias, out, flow2, B, H, W, out_planes, flow_planes):
+    """flow_encode that also writes the planes a split3 consumer reads: out_planes = image of out[:, :Co]; flow_planes = the column slice
+    of the GRU input's planes that starts at the flow's two channels' 32-channel chunk (its offset inside the chunk from flow2's column)."""
+    fp, fcol = flow_planes
+    check(lib.st_flow_encode_split3(_pc(coords1), _pc(w98), _pc(bias), _p(out), _ld(out), _p(flow2), _ld(flow2), B, H, W, w98.shape[1],
+                                    C.c_void_p(out_planes.ptr()), out_planes.pstride, out_planes.rows,
+                                    C.c_void_p(fp.t.data_ptr()), fp.pstride, fp.rows, int(fcol), _stream()), "st_flow_encode_split3")
+    return out
+
+
 def cost_lookup(maps, coords, out, Nq, H2, W2, r=4):
     check(lib.st_cost_lookup(_p(maps), _p(coords), _p(out), _ld(out), Nq, H2, W2, r, _stream()), "st_cost_lookup")
     return out
@@ -375,6 +461,25 @@ def gma_aggregate(attn, mf, w_v, gamma, vT, out, B, N):
     check(lib.st_gma_aggregate(_pc(attn), _p(mf), _ld(mf), _pc(w_v), _p(gamma), _pc(vT), _p(out), _ld(out), B, N,
                                *_ws(mf.device), _stream()), "st_gma_aggregate")
     return out
+
+
+def gma_aggregate_split3(attn_planes, mf, w_v, gamma, vT, vT_planes, out, out_planes, B, N):
+    """gma_aggregate on planes: attn_planes = split3_pack(attn [B*N, N]); vT_planes scratch Planes(B*128, N); out also -> out_planes (column slice)."""
+    check(lib.st_gma_aggregate_split3(C.c_void_p(attn_planes.ptr()), attn_planes.pstride, _p(mf), _ld(mf), _pc(w_v), _p(gamma), _pc(vT),
+                                      C.c_void_p(vT_planes.ptr()), vT_planes.pstride, _p(out), _ld(out), C.c_void_p(out_planes.t.data_ptr()),
+                                      out_planes.pstride, out_planes.rows, out_planes.c0, B, N, *_ws(mf.device), _stream()), "st_gma_aggregate_split3")
+    return out
+
+
+def sepconv_gru_split3(hxA, hxA_planes, hxB_planes, zbuf, tab1, tab2, w_zr1, w_q1, w_zr2, w_q2, B, H, W):
+    """sepconv_gru on planes (st_sepconv_gru_split3): w_* are split3_pack images of the fp32 operator's weights."""
+    assert hxA_planes.pstride == hxB_planes.pstride and hxA_planes.rows == hxB_planes.rows and hxA_planes.C == _ld(hxA)
+    assert w_zr1.pstride == w_zr2.pstride and w_q1.pstride == w_q2.pstride
+    check(lib.st_sepconv_gru_split3(_p(hxA), _ld(hxA), C.c_void_p(hxA_planes.t.data_ptr()), C.c_void_p(hxB_planes.t.data_ptr()),
+                                    hxA_planes.pstride, hxA_planes.rows, _pc(zbuf), _p(tab1), _p(tab2), _ld(tab1),
+                                    C.c_void_p(w_zr1.ptr()), C.c_void_p(w_q1.ptr()), C.c_void_p(w_zr2.ptr()), C.c_void_p(w_q2.ptr()),
+                                    w_zr1.pstride, w_q1.pstride, B, H, W, *_ws(hxA.device), _stream()), "st_sepconv_gru_split3")
+    return hxA
 
 
 def sepconv_gru(hxA, hxB, zbuf, tab1, tab2, w_zr1, w_q1, w_zr2, w_q2, B, H, W):

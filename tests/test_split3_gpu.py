@@ -1,0 +1,240 @@
+"""The exact-split contraction (st_gemm_desc.split3, csrc/gemm_split3.h) through the C-ABI: plane format, the six-product kernel against
+the fp32-MFMA kernel and the fp64 product, plane emission by every epilogue mode, the split3 operators against their fp32 twins.
+
+Bar: the split is EXACT (hi + mid + lo == x bit for bit); the contraction's error against fp64 is no larger than 1.25x the fp32 kernel's
+(measured 0.77-0.87x, profiles/r6_split3_probe.json); emitted planes equal st_split3_pack of the fp32 result bit for bit."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from _measure import check  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import stitch_amd
+    assert torch.cuda.is_available()
+    return stitch_amd.ops
+
+
+def g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def unpack(planes, rows=None):
+    """Planes -> fp64 [rows, ncols] = hi + mid + lo (exact in fp64)"""
+    t = planes.t[:, planes.c0 // 32:(planes.c0 + planes.ncols + 31) // 32].double().sum(0)       # [chunks, rows, 32]
+    x = t.permute(1, 0, 2).reshape(planes.rows, -1)[:, :planes.ncols]
+    return x if rows is None else x[:rows]
+
+
+def test_split3_pack_is_exact(ops):
+    x = torch.randn(300, 96, generator=g(1)) * torch.logspace(-20, 20, 96)[None, :]
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.4e38, -3.4e38, 1e-30, 2.0 ** -100])
+    p = ops.split3_pack(dev(x))
+    assert torch.equal(unpack(p).cpu(), x.double())
+    # the three parts are bf16 with decreasing magnitude: |mid| <= 2^-8 |hi|, |lo| <= 2^-16 |hi| (+ a rounding ulp)
+    hi, mid, lo = (p.t[i].float().abs() for i in range(3))
+    assert bool((mid <= hi * 2.0 ** -7).all()) and bool((lo <= hi * 2.0 ** -15).all())
+    # non-finite values stay in hi alone
+    y = torch.tensor([[float("inf"), float("-inf"), float("nan")] + [1.0] * 29])
+    q = ops.split3_pack(dev(y))
+    assert torch.isinf(q.t[0, 0, 0, :2]).all() and torch.isnan(q.t[0, 0, 0, 2]) and bool((q.t[1:, 0, 0, :3] == 0).all())
+
+
+def conv_ref64(x, w, B, H, W, Cin, kh, kw):
+    N = w.shape[0]
+    x64 = x.double().view(B, H, W, Cin)
+    w64 = w.double().view(N, kh, kw, Cin)
+    ref = torch.zeros(B, H, W, N, dtype=torch.float64, device=x.device)
+    for ky in range(kh):
+        for kx in range(kw):
+            dy, dx = ky - kh // 2, kx - kw // 2
+            ylo, yhi, xlo, xhi = max(0, -dy), min(H, H - dy), max(0, -dx), min(W, W - dx)
+            ref[:, ylo:yhi, xlo:xhi] += x64[:, ylo + dy:yhi + dy, xlo + dx:xhi + dx] @ w64[:, ky, kx].t()
+    return ref.view(-1, N)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,N,kh,kw,tile,split", [
+    (2, 16, 16, 128, 128, 1, 5, 0, 0), (2, 16, 16, 128, 128, 5, 1, 34, 1), (1, 24, 40, 64, 126, 3, 3, 34, 1), (1, 24, 40, 64, 126, 3, 3, 32, 1),
+    (2, 32, 32, 96, 256, 3, 3, 33, 1), (1, 16, 16, 256, 64, 3, 3, 34, 3), (1, 64, 64, 384, 256, 1, 5, 32, 1), (1, 8, 12, 32, 40, 1, 1, 31, 1),
+    (1, 64, 64, 384, 256, 5, 1, 36, 1), (1, 16, 32, 128, 192, 3, 3, 35, 2)])
+def test_split3_conv_vs_fp32_kernel_and_fp64(ops, B, H, W, Cin, N, kh, kw, tile, split):
+    x = dev(torch.randn(B * H * W, Cin, generator=g(2)))
+    w = dev(torch.randn(N, kh * kw * Cin, generator=g(3)) / (kh * kw * Cin) ** 0.5)
+    bias = dev(torch.randn(N, generator=g(4)))
+    geom = (B, H, W, kh, kw, 1, 1, kh // 2, kw // 2)
+    ref = conv_ref64(x, w, B, H, W, Cin, kh, kw) + bias.double()
+    oe, os_ = torch.empty(B * H * W, N, device="cuda"), torch.empty(B * H * W, N, device="cuda")
+    ops.conv_gemm(x, w, oe, geom=geom, bias=bias)
+    ops.conv_gemm(ops.split3_pack(x), ops.split3_pack(w), os_, geom=geom, bias=bias, tile=tile, split_k=split)
+    torch.cuda.synchronize()
+    scale = ref.pow(2).mean().sqrt()
+    e_exact, e_split = ((oe.double() - ref).pow(2).mean().sqrt() / scale).item(), ((os_.double() - ref).pow(2).mean().sqrt() / scale).item()
+    check(f"split3_conv_{kh}x{kw}_{Cin}_{N}_t{tile}_rms_vs_fp64", e_split, 1.25 * e_exact)
+    assert ((os_.double() - ref).abs().max() / scale).item() < 1.5 * ((oe.double() - ref).abs().max() / scale).item() + 1e-7
+
+
+def test_split3_batched_plain_matrix_and_second_source(ops):
+    # batched A . W^T (the aggregate's form) and the q conv's two-source A
+    Bb, M, N, K = 3, 160, 96, 512
+    a, w = dev(torch.rand(Bb, M, K, generator=g(5))), dev(torch.randn(Bb, N, K, generator=g(6)))
+    out = torch.empty(Bb, M, N, device="cuda")
+    ap, wp = ops.split3_pack(a.view(Bb * M, K)), ops.split3_pack(w.view(Bb * N, K))
+    ops.conv_gemm(ap, wp, out.view(Bb * M, N)[:M], M=M, N=N, batch=Bb, bsa=M * 32, bsw=N * 32, bsc=M * N)
+    torch.cuda.synchronize()
+    ref = a.double() @ w.double().transpose(1, 2)
+    assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    B, H, W, Cin, N2 = 1, 16, 16, 256, 128
+    x1, x2 = dev(torch.randn(B * H * W, Cin, generator=g(7))), dev(torch.randn(B * H * W, Cin, generator=g(8)))
+    w2 = dev(torch.randn(N2, 5 * Cin, generator=g(9)) / 36.0)
+    o1, o2 = torch.empty(B * H * W, N2, device="cuda"), torch.empty(B * H * W, N2, device="cuda")
+    geom = (B, H, W, 1, 5, 1, 1, 0, 2)
+    ops.conv_gemm(x1, w2, o1, geom=geom, a2=x2, a2_channels=128)
+    ops.conv_gemm(ops.split3_pack(x1), ops.split3_pack(w2), o2, geom=geom, a2=ops.split3_pack(x2), a2_channels=128)
+    torch.cuda.synchronize()
+    assert ((o1 - o2).abs().max() / o1.abs().max()).item() < 2e-6
+
+
+@pytest.mark.parametrize("mode", ["store_fp32_kernel", "store_split3", "splitk", "gru", "zr", "axpy_batched", "pair"])
+def test_epilogues_emit_the_planes_of_their_result(ops, mode):
+    """st_gemm_desc.c_planes: whatever kernel and epilogue mode, the planes equal st_split3_pack(fp32 result) bit for bit."""
+    B, H, W, Cin = 2, 16, 16, 128
+    R = B * H * W
+    geom = (B, H, W, 3, 3, 1, 1, 1, 1)
+    x = dev(torch.randn(R, Cin, generator=g(10)))
+    xp = ops.split3_pack(x)
+    wide = ops.Planes(R, 384, "cuda")
+    wide.t.zero_()
+
+    def same(planes_slice, fp32_2d):
+        torch.cuda.synchronize()
+        assert torch.equal(unpack(planes_slice).cpu(), fp32_2d.double().cpu())
+        want = ops.split3_pack(fp32_2d.contiguous())
+        assert torch.equal(planes_slice.t[:, planes_slice.c0 // 32:(planes_slice.c0 + planes_slice.ncols) // 32].cpu(), want.t.cpu())
+
+    if mode in ("store_fp32_kernel", "store_split3", "splitk"):
+        N = 96
+        w = dev(torch.randn(N, 9 * Cin, generator=g(11)) / 34.0)
+        out = torch.empty(R, N, device="cuda")
+        if mode == "store_fp32_kernel":
+            ops.conv_gemm(x, w, out, geom=geom, act="relu", out_planes=wide.cols(128, 224))
+        else:
+            ops.conv_gemm(xp, ops.split3_pack(w), out, geom=geom, act="relu", out_planes=wide.cols(128, 224), tile=34,
+                          split_k=3 if mode == "splitk" else 1)
+        same(wide.cols(128, 224), out)
+        assert bool((wide.t[:, :4] == 0).all()) and bool((wide.t[:, 7:] == 0).all())          # neighbours untouched
+    elif mode == "gru":
+        N = 128
+        w = dev(torch.randn(N, 9 * Cin, generator=g(12)) / 34.0)
+        z, h = dev(torch.rand(R, N, generator=g(13))), dev(torch.randn(R, 384, generator=g(14)))
+        h0 = h.clone()
+        ops.conv_gemm(xp, ops.split3_pack(w), h[:, :128], geom=geom, act="tanh", epi="gru", aux1=z, aux2=h[:, :128], out_planes=wide.cols(0, 128))
+        same(wide.cols(0, 128), h[:, :128])
+        ref = torch.empty(R, N, device="cuda")
+        ops.conv_gemm(x, w, ref, geom=geom, act="tanh", epi="gru", aux1=z, aux2=h0[:, :128].contiguous())
+        torch.cuda.synchronize()
+        assert (ref - h[:, :128]).abs().max().item() < 2e-6
+    elif mode == "zr":
+        w = dev(torch.randn(256, 9 * Cin, generator=g(15)) / 34.0)
+        hh = dev(torch.randn(R, 128, generator=g(16)))
+        zb, rh, rh_ref, zb_ref = (torch.full((R, 128), 7.0, device="cuda") for _ in range(4))
+        ops.conv_gemm(xp, ops.split3_pack(w), zb, geom=geom, act="sigmoid", epi="zr", aux1=hh, out2=rh, out_planes=wide.cols(0, 128), no_f32=True)
+        ops.conv_gemm(x, w, zb_ref, geom=geom, act="sigmoid", epi="zr", aux1=hh, out2=rh_ref)
+        torch.cuda.synchronize()
+        assert bool((rh == 7.0).all())                                  # c_no_f32: the fp32 r*h is not written ...
+        assert (zb - zb_ref).abs().max().item() < 2e-6                  # ... z is
+        assert (unpack(wide.cols(0, 128)) - rh_ref.double()).abs().max().item() < 2e-6
+    elif mode == "axpy_batched":
+        Bb, M, N, K = 2, 128, 128, 256
+        a, vt = dev(torch.rand(Bb, M, K, generator=g(17))), dev(torch.randn(Bb, N, K, generator=g(18)))
+        mf, gamma = dev(torch.randn(Bb * M, 128, generator=g(19))), dev(torch.tensor([0.3]))
+        out = torch.empty(Bb * M, N, device="cuda")
+        big = ops.Planes(Bb * M, 384, "cuda")
+        ops.conv_gemm(ops.split3_pack(a.view(Bb * M, K)), ops.split3_pack(vt.view(Bb * N, K)), out[:M], M=M, N=N, batch=Bb, bsa=M * 32, bsw=N * 32,
+                      bsc=M * N, bsx1=M * 128, epi="axpy", aux1=mf[:M], scale_ptr=gamma, out_planes=big.cols(256, 384), plane_batch_rows=M)
+        same(big.cols(256, 384), out)
+        ref = mf.double().view(Bb, M, N) + 0.3 * (a.double() @ vt.double().transpose(1, 2))
+        assert ((out.double().view(Bb, M, N) - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    else:
+        w0, w1 = dev(torch.randn(192, 9 * Cin, generator=g(20)) / 34.0), dev(torch.randn(64, 9 * Cin, generator=g(21)) / 34.0)
+        x1 = dev(torch.randn(R, Cin, generator=g(22)))
+        out = torch.zeros(R, 256, device="cuda")
+        ops.conv_gemm_pair((xp, ops.split3_pack(w0), out[:, :192], dict(geom=geom, act="relu", out_planes=wide.cols(0, 192))),
+                           (ops.split3_pack(x1), ops.split3_pack(w1), out[:, 192:], dict(geom=geom, act="relu", out_planes=wide.cols(192, 256))))
+        same(wide.cols(0, 256), out)
+        ref = torch.empty(R, 256, device="cuda")
+        ops.conv_gemm(x, w0, ref[:, :192], geom=geom, act="relu")
+        ops.conv_gemm(x1, w1, ref[:, 192:], geom=geom, act="relu")
+        torch.cuda.synchronize()
+        assert ((ref - out).abs().max() / ref.abs().max()).item() < 2e-6
+
+
+def test_flow_encode_split3_planes(ops):
+    B, H, W = 2, 12, 16
+    R = B * H * W
+    coords = dev(torch.randn(R, 2, generator=g(23)) * 3 + 5)
+    w98, b = dev(torch.randn(98, 128, generator=g(24)) * 0.1), dev(torch.randn(128, generator=g(25)) * 0.1)
+    o0, o1 = torch.empty(R, 128, device="cuda"), torch.empty(R, 128, device="cuda")
+    wide0, wide1 = torch.zeros(R, 384, device="cuda"), torch.zeros(R, 384, device="cuda")
+    ops.flow_encode(coords, w98, b, o0, wide0[:, 254:256], B, H, W)
+    pl, widep = ops.Planes(R, 128, "cuda"), ops.Planes(R, 384, "cuda")
+    widep.t.zero_()
+    ops.flow_encode_split3(coords, w98, b, o1, wide1[:, 254:256], B, H, W, pl, (widep, 254))
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1) and torch.equal(wide0, wide1)
+    assert torch.equal(unpack(pl).cpu(), o1.double().cpu())
+    assert torch.equal(unpack(widep).cpu(), wide1.double().cpu())
+
+
+def test_split3_operators_against_their_fp32_twins(ops):
+    """st_sepconv_gru_split3 / st_gma_aggregate_split3 (gru.py:44-59, gma.py:102-115) against st_sepconv_gru / st_gma_aggregate."""
+    B, H, W = 2, 16, 16
+    N = H * W
+    R = B * N
+    hx = dev(torch.randn(R, 384, generator=g(30)))
+    hx[:, :128] = hx[:, :128].tanh()
+    tabs = [dev(torch.randn(R, 384, generator=g(31 + i)) * 0.3) for i in range(2)]
+    wzr = [dev(torch.randn(256, 5 * 384, generator=g(33 + i)) * 0.02) for i in range(2)]
+    wq = [dev(torch.randn(128, 5 * 384, generator=g(35 + i)) * 0.02) for i in range(2)]
+    hA, hB, zb = hx.clone(), torch.zeros(R, 384, device="cuda"), torch.empty(R, 128, device="cuda")
+    ops.sepconv_gru(hA, hB, zb, tabs[0], tabs[1], wzr[0], wq[0], wzr[1], wq[1], B, H, W)
+    hA3, zb3 = hx.clone(), torch.empty(R, 128, device="cuda")
+    pA, pB = ops.split3_pack(hx), ops.Planes(R, 384, "cuda")
+    ops.sepconv_gru_split3(hA3, pA, pB, zb3, tabs[0], tabs[1], *(ops.split3_pack(t) for t in (wzr[0], wq[0], wzr[1], wq[1])), B, H, W)
+    torch.cuda.synchronize()
+    check("split3_sepconv_gru_vs_fp32_operator", (hA3[:, :128] - hA[:, :128]).abs().max().item(), 3e-6)
+    assert torch.equal(hA3[:, 128:], hx[:, 128:])
+    assert torch.equal(unpack(pA.cols(0, 128)).cpu(), hA3[:, :128].double().cpu())              # the new state's planes
+    assert torch.equal(unpack(pA.cols(128, 384)).cpu(), hx[:, 128:].double().cpu())              # x untouched
+    # aggregate
+    attn = torch.softmax(dev(torch.randn(B, N, N, generator=g(40))) * 2, -1)
+    w_v, gamma = dev(torch.randn(128, 128, generator=g(41)) / 11.3), dev(torch.tensor([0.37]))
+    wide, wide3 = hx.clone(), hx.clone()
+    vT, vT3 = torch.empty(B, 128, N, device="cuda"), torch.empty(B, 128, N, device="cuda")
+    ops.gma_aggregate(attn, wide[:, 128:256], w_v, gamma, vT, wide[:, 256:], B, N)
+    pW = ops.split3_pack(hx)
+    ops.gma_aggregate_split3(ops.split3_pack(attn.view(B * N, N)), wide3[:, 128:256], w_v, gamma, vT3, ops.Planes(B * 128, N, "cuda"), wide3[:, 256:],
+                             pW.cols(256, 384), B, N)
+    torch.cuda.synchronize()
+    assert torch.equal(vT, vT3)
+    check("split3_gma_aggregate_vs_fp32_operator", ((wide3[:, 256:] - wide[:, 256:]).abs().max() / wide[:, 256:].abs().max()).item(), 2e-6)
+    assert torch.equal(unpack(pW.cols(256, 384)).cpu(), wide3[:, 256:].double().cpu())
+
+
+def test_split3_rejects_what_it_cannot_run(ops):
+    x, w = dev(torch.randn(64, 48)), dev(torch.randn(32, 48))
+    out = torch.empty(64, 32, device="cuda")
+    with pytest.raises(Exception):
+        ops.split3_pack(x)                                    # C % 32 != 0
+    xp, wp = ops.split3_pack(dev(torch.randn(64, 64))), ops.split3_pack(dev(torch.randn(32, 64)))
+    with pytest.raises(ops.StitchErrorBase):
+        ops.conv_gemm(xp, wp, out, tile=13)                   # an fp32-kernel tile
+    with pytest.raises(ops.StitchErrorBase):                      # planes of a result whose rows are not whole 32-row tiles
+        ops.conv_gemm(dev(torch.randn(40, 64)), dev(torch.randn(32, 64)), torch.empty(40, 32, device="cuda"), out_planes=ops.Planes(40, 32, "cuda"))
