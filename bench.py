@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = vector fp32 peak
 HBM_PEAK_GBS = 8000.0
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD), no sparsity
 
 
 def parse_args(argv=None):
@@ -120,9 +121,13 @@ def instrumented_step(run_step):
             a_rows = d.M if d.kh * d.kw <= 1 else (d.M // max(1, d.Ho * d.Wo)) * d.H * d.W       # conv: input pixels
             if plan[0] in (5, 6):       # fused row kernels, reported as M x 128 L x 128 / M x 2 hidden x 128: rows in, weights, rows out
                 abytes = 4.0 * (2 * d.M * 128 + d.N * d.K) + (4.0 * d.M * 128 if plan[0] == 6 else 0.0)      # (+ the MLP's residual re-read)
+            elif d.split3:              # exact-split operands: three bf16 planes = 6 bytes per element of A and W; C fp32 (unless c_no_f32)
+                abytes = nb * (6.0 * (a_rows * d.Cin + d.N * d.K) + (0.0 if d.c_no_f32 else 4.0 * d.M * d.N))
             else:
                 abytes = 4.0 * nb * (a_rows * d.Cin + d.N * d.K + d.M * d.N * (2 if d.c_t else 1))          # A + W + C (+ transposed copy), fp32
-            rec.append((2.0 * d.M * d.N * d.K * nb, abytes, open_ev.pop(), ev))
+            if d.c_planes:              # the result also leaves as planes
+                abytes += 6.0 * nb * d.M * (d.N // 2 if d.epi == 5 else d.N)
+            rec.append((2.0 * d.M * d.N * d.K * nb, abytes, open_ev.pop(), ev, bool(d.split3)))
 
     lib.st_set_gemm_observer(C.cast(observer, C.c_void_p), None)
     st = torch.cuda.current_stream()
@@ -145,8 +150,10 @@ def instrumented_step(run_step):
         lib.st_set_gemm_observer(None, None)
     ov = sorted(e0.elapsed_time(e1) for e0, e1 in empties)[len(empties) // 2]
     raw = [r[2].elapsed_time(r[3]) for r in rec]
+    s3 = [(r, t) for r, t in zip(rec, raw) if r[4]]
     return dict(flops=sum(r[0] for r in rec), ms_raw=sum(raw), ms=sum(max(0.0, t - ov) for t in raw), launches=len(rec),
-                alg_bytes=sum(r[1] for r in rec), bracket_overhead_us=1e3 * ov)
+                alg_bytes=sum(r[1] for r in rec), bracket_overhead_us=1e3 * ov,
+                split3_flops=sum(r[0] for r, _ in s3), split3_ms=sum(max(0.0, t - ov) for _, t in s3), split3_launches=len(s3))
 
 
 def provenance(path):
@@ -479,8 +486,25 @@ def worker(args):
         inst = instrumented_step((lambda: model(a, b, type="test_out")) if big else (lambda: model(a, b, type="test_eval")))
         flops, gemm_ms, launches, abytes = inst["flops"], inst["ms"], inst["launches"], inst["alg_bytes"]
         tf = flops / gemm_ms / 1e9
+        split3_on = inst["split3_launches"] > 0
+        s3_tf = inst["split3_flops"] / inst["split3_ms"] / 1e9 if split3_on else None
+        f32_ms = gemm_ms - inst["split3_ms"]
+        value_exact = None
+        if split3_on and world == 1 and not big and nb == 1 and not args.eager and os.environ.get("ST_BENCH_CHILD") != "1":
+            # the same command on the fp32-MFMA kernels of rounds 1-5 (ST_SPLIT3=0), in a child process (the switch is read at import)
+            log("child run with ST_SPLIT3=0 (value_exact_fp32)")
+            env = dict(os.environ, ST_SPLIT3="0", ST_BENCH_CHILD="1")
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.steps), "--warmup", str(args.warmup), "--streams", str(args.streams),
+                   "--harness", "none", "--no-cpu-baseline", "--no-corr-roofline"]
+            try:
+                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=400)
+                for ln in cp.stdout.splitlines():
+                    if ln.startswith("{") and '"metric"' in ln:
+                        value_exact = json.loads(ln)["value"]
+            except Exception as ex:       # the headline does not depend on it
+                log(f"value_exact_fp32 child failed: {ex}")
         traffic, tsrc = None, None             # HBM bytes per step of the GEMM family from the committed PMC passes
-        for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for name in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and not big and nb == 1:
                 t = json.load(open(tpath))
@@ -490,7 +514,7 @@ def worker(args):
                 break
         # per-kernel time of the same command from the committed rocprofv3 pass (tools/final_prof.sh -> profiles/r5_kernel_summary.json)
         prof, psrc = None, None
-        for name in ("r5_kernel_summary.json", "r4_kernel_summary.json", "r3_kernel_summary.json"):
+        for name in ("r6_kernel_summary.json", "r5_kernel_summary.json", "r4_kernel_summary.json", "r3_kernel_summary.json"):
             ppath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(ppath) and not big and nb == 1:
                 prof = json.load(open(ppath))
@@ -502,7 +526,11 @@ def worker(args):
             "metric": "stitched image-pairs/s at 512x512" if not big else "stitched image-pairs/s at 1024x1024",
             "value": world * args.steps * nb / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (decoder contractions: exact 3xbf16 split of both operands, 6 products on the bf16 matrix cores, fp32 accumulate -- error vs fp64 "
+                      "0.83x the fp32 MFMA chain's; everything else fp32)") if split3_on else "f32",
+            "value_exact_fp32": value_exact, "data": "synthetic",
+            "effective_warmup_steps": nstreams + settle + max(args.warmup, nstreams),
             "config": {"workload": wl, "pairs_per_step_per_gpu": nb,
                        "launch": "eager" if args.eager else ("hipGraph replay of the network part + eager canvas part" if big else "hipGraph replay"),
                        "pairs_in_flight": nstreams * nb,
@@ -514,8 +542,17 @@ def worker(args):
             "harness": harness,
             "value_1_in_flight": None if dt1 is None else world * max(10, args.steps // 2) * nb / dt1,
             "per_rank_pairs_per_s": {"min": min(per_rank_pairs_s), "max": max(per_rank_pairs_s), "ranks": len(per_rank_pairs_s)},
-            "roofline": {"bound": "mfma", "kernel": "fp32 MFMA GEMM family: conv_gemm_dma_kernel + rowstream_gemm_kernel + rowmlp128_kernel + rowchain128_kernel + conv_gemm_kernel + skinny / narrow variants + split-K reducers (every st_conv_gemm / st_mlp128 / st_linear_chain128 launch of one step)",
+            "roofline": {"bound": "mfma", "kernel": "GEMM family: conv_gemm_split3_kernel (decoder contractions, exact 3xbf16 split on the bf16 matrix cores) + the fp32-MFMA kernels conv_gemm_dma_kernel + rowstream_gemm_kernel + rowmlp128_kernel + rowchain128_kernel + conv_gemm_kernel + skinny / narrow variants + split-K reducers (every st_conv_gemm / st_mlp128 / st_linear_chain128 launch of one step)",
                          "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                         "frac_note": "fp32-EQUIVALENT FLOPs (2 M N K per launch) of the whole family over its kernel time against the fp32-MFMA peak: the split3 launches execute 6 bf16 products per fp32 product on the 16x faster bf16 pipe, so this fraction is not bounded by 1 for them -- `split3` and `fp32_mfma` below price each part against its own pipe",
+                         "split3": None if not split3_on else {
+                             "kernel": "conv_gemm_split3_kernel / conv_gemm_split3_kernel64 / conv_gemm_split3_pair_kernel (csrc/gemm_split3.h)",
+                             "launches_per_step": inst["split3_launches"], "kernel_ms_per_step": inst["split3_ms"], "fp32_equivalent_tflops": s3_tf,
+                             "bound": "mfma", "achieved": 6.0 * s3_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (bf16 products executed: 6 per fp32 product)",
+                             "frac": 6.0 * s3_tf / BF16_MFMA_PEAK_TFLOPS,
+                             "note": "in-kernel: MFMA-bound at the clock the chip holds under this load (1.47 GHz in the K loop with the DMA ring running, 2.2 GHz without: tools/split3_clock.py, profiles/r6_split3_clock.txt), 0.49 of the matrix cycles of a 2.03 GHz dispatch (profiles/r6_split3_sq_counters.txt)"},
+                         "fp32_mfma": {"kernel_ms_per_step": f32_ms, "achieved": (flops - inst["split3_flops"]) / f32_ms / 1e9, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                       "frac": (flops - inst["split3_flops"]) / f32_ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": launches - inst["split3_launches"]},
                          "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)", "traffic_source": tsrc,
                          "algorithmic_bytes": abytes, "launches_per_step": launches, "gflop_per_step": flops / 1e9,
                          "kernel_ms_per_step": gemm_ms, "kernel_ms_per_step_uncorrected": inst["ms_raw"],

@@ -11,6 +11,8 @@ reference's other branches raise ``NotImplementedError`` here exactly where they
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -54,14 +56,21 @@ class FlowHomoAdpater(nn.Module):
         copies next to live parameters.  Every graph holder (``GraphedForward``, ``GraphedTestOut``, ``evaluate.EvalPipeline``) stores this
         value at capture and re-captures on mismatch.  ``deep=True`` adds the parameters' in-place version counters (``p.data`` writes,
         optimiser steps) and storage addresses -- 699 tensors, checked once per harness run rather than per pair."""
-        g = (getattr(self.homo_backbone, "_gen", 0), getattr(self.flow_backbone, "_gen", 0))
         if deep:
             v = a = 0
             for t in self.parameters():
                 v += t._version
                 a ^= t.data_ptr()
-            g += (v, a)
-        return g
+            seen = getattr(self, "_deep_seen", None)
+            if seen != (v, a):
+                # an in-place write (or the first deep check after the backbones packed): the PACKED copies (BatchNorm folded in, fused q|k|v,
+                # split3 planes) are stale too -- drop them, which also bumps the generation the shallow holders compare
+                if seen is not None or getattr(self.homo_backbone, "_pk", None) is not None or getattr(self.flow_backbone, "_pk", None) is not None:
+                    self.homo_backbone._invalidate()
+                    self.flow_backbone._invalidate()
+                self._deep_seen = (v, a)
+            return (getattr(self.homo_backbone, "_gen", 0), getattr(self.flow_backbone, "_gen", 0), v, a)
+        return (getattr(self.homo_backbone, "_gen", 0), getattr(self.flow_backbone, "_gen", 0))
 
     # ------------------------------------------------------------------ small host-side constants
     def _mat(self, dev, key, rows):
@@ -105,10 +114,14 @@ class FlowHomoAdpater(nn.Module):
         return both[:B], both[B:]
 
     def forward(self, input1_tensor, input2_tensor, type="train", pad_mode="constant", preprocess_callback=None):
-        if not input1_tensor.is_cuda:
-            raise RuntimeError("FlowHomoAdpater (gfx950) needs CUDA/HIP tensors: there is no CPU fallback")
-        input1_tensor = input1_tensor.float().contiguous()
-        input2_tensor = input2_tensor.float().contiguous()
+        # The reference's callers go through nn.DataParallel and hand over whatever the loader produced, CPU tensors included (out.py:197,
+        # evaluate.py:43): the inputs move to the module's device, as DataParallel's scatter does.  The COMPUTE has no CPU path: a module
+        # that itself sits on the CPU still raises.
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("FlowHomoAdpater (gfx950) runs on the MI355X HIP kernels only: move the module to cuda (there is no CPU fallback)")
+        input1_tensor = input1_tensor.to(dev, non_blocking=True).float().contiguous()
+        input2_tensor = input2_tensor.to(dev, non_blocking=True).float().contiguous()
         with torch.no_grad():
             if type == "test_out":
                 return self.test_out_forward(input1_tensor, input2_tensor, pad_mode=pad_mode,
@@ -182,6 +195,9 @@ class FlowHomoAdpater(nn.Module):
         B, _, img_h, img_w = input1_tensor.shape
         if B != 1:
             raise NotImplementedError("test_out shares one data-dependent canvas: batch must be 1 (as in out.py:37)")
+        pre_out = None
+        if os.environ.get("ST_EXP_PREALLOC") == "1":           # experiment: the two flow outputs do not reuse blocks the networks freed
+            pre_out = (torch.empty((B, 2, img_h, img_w), device=dev), torch.empty((B, 2, img_h, img_w), device=dev))
         a512 = ops.resize_bilinear(input1_tensor, 512, 512, False)                                     # :204-205
         b512 = ops.resize_bilinear(input2_tensor, 512, 512, False)
         motion = self.predict_homo(a512, b512).contiguous()
@@ -194,12 +210,14 @@ class FlowHomoAdpater(nn.Module):
         warp2_512 = out_H[:, 0:3].contiguous()
         warp_mask_512 = ops.mean_threshold(out_H[:, 3:6].contiguous(), 0.5)                            # :233-234
         flow512, back512 = self.predict_flow_pair(a512, warp2_512)                                     # :236 and :326, one batch
-        residual = ops.resize_bilinear(flow512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))  # :241
-        back = ops.resize_bilinear(back512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)))
+        residual = ops.resize_bilinear(flow512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)), out=pre_out[0] if pre_out else None)  # :241
+        back = ops.resize_bilinear(back512, img_h, img_w, True, div=(512 / float(img_w), 512 / float(img_h)), out=pre_out[1] if pre_out else None)
         H = torch.empty((B, 3, 3), device=dev)
         ops.dlt4(self._corners(dev, float(img_w), float(img_h)), motion, H, B, img_w / 512.0, img_h / 512.0, 1.0)  # :244-253
         bounds = torch.empty((4,), device=dev)
         ops.mesh_bounds(H, bounds, img_w, img_h)                                                       # :254-266
+        if os.environ.get("ST_EXP_KEEP") == "1":                  # diagnostics (tools/graph_race_stress.py): the 512 x 512 flows as extra static outputs
+            return dict(residual=residual, back=back, H=H, bounds=bounds, warp2_512=warp2_512, warp_mask_512=warp_mask_512, flow512=flow512, back512=back512)
         return dict(residual=residual, back=back, H=H, bounds=bounds, warp2_512=warp2_512, warp_mask_512=warp_mask_512)
 
     def _test_out_canvas(self, input1_tensor, input2_tensor, nets):

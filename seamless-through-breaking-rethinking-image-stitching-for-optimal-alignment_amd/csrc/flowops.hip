@@ -126,11 +126,18 @@ __global__ __launch_bounds__(512) void flow_encode_kernel(const float* __restric
         if (x < W && cok) {
             const float o = fmaxf(acc[p], 0.f);
             out[(img + (size_t)y * W + x) * ldo + c] = o;
-            if (out_planes) {        // the blocked bf16 planes a split3 consumer reads (st_gemm_desc.split3): 32 lanes = one 64-byte chunk row
+            if (out_planes) {        // the blocked bf16 planes a split3 consumer reads (st_gemm_desc.split3): 32 lanes = one 64-byte chunk row;
+                // neighbouring lanes (channels c, c ^ 1; Co % 32 == 0, so both are inside) exchange halves and the even one stores the dword
                 __bf16 h, m, l;
                 st_split3(o, h, m, l);
-                __bf16* pp = out_planes + ((size_t)(c >> 5) * out_prows + img + (size_t)y * W + x) * 32 + (c & 31);
-                pp[0] = h; pp[out_pstride] = m; pp[2 * out_pstride] = l;
+                const unsigned ph = st_bf16_bits(h), pm = st_bf16_bits(m), pl = st_bf16_bits(l);
+                const unsigned nh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ph, 0xB1, 0xF, 0xF, false);
+                const unsigned nm = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0xB1, 0xF, 0xF, false);
+                const unsigned nl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pl, 0xB1, 0xF, 0xF, false);
+                if (!(c & 1)) {
+                    unsigned* pp = reinterpret_cast<unsigned*>(out_planes + ((size_t)(c >> 5) * out_prows + img + (size_t)y * W + x) * 32 + (c & 31));
+                    pp[0] = ph | (nh << 16); pp[out_pstride / 2] = pm | (nm << 16); pp[out_pstride] = pl | (nl << 16);
+                }
             }
         }
     }
@@ -139,12 +146,13 @@ __global__ __launch_bounds__(512) void flow_encode_kernel(const float* __restric
         const size_t r = img + (size_t)y * W + tx * 8 + lane;
         flow2[r * ld2] = f.x; flow2[r * ld2 + 1] = f.y;
         if (flow_planes) {           // channels flow_col, flow_col + 1 (same chunk: flow_col is even) of the GRU input's planes
-            __bf16 h, m, l;
-            __bf16* pp = flow_planes + ((size_t)(flow_col >> 5) * flow_prows + r) * 32 + (flow_col & 31);
-            st_split3(f.x, h, m, l);
-            pp[0] = h; pp[flow_pstride] = m; pp[2 * flow_pstride] = l;
-            st_split3(f.y, h, m, l);
-            pp[1] = h; pp[flow_pstride + 1] = m; pp[2 * flow_pstride + 1] = l;
+            __bf16 hx, mx, lx, hy, my, ly;
+            unsigned* pp = reinterpret_cast<unsigned*>(flow_planes + ((size_t)(flow_col >> 5) * flow_prows + r) * 32 + (flow_col & 31));
+            st_split3(f.x, hx, mx, lx);
+            st_split3(f.y, hy, my, ly);
+            pp[0] = st_bf16_bits(hx) | ((unsigned)st_bf16_bits(hy) << 16);
+            pp[flow_pstride / 2] = st_bf16_bits(mx) | ((unsigned)st_bf16_bits(my) << 16);
+            pp[flow_pstride] = st_bf16_bits(lx) | ((unsigned)st_bf16_bits(ly) << 16);
         }
     }
 }

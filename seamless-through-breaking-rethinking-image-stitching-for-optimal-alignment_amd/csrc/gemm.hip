@@ -71,12 +71,18 @@ __device__ __forceinline__ float gemm_epilogue(const st_gemm_desc& d, int m, int
 }
 
 // st_gemm_desc.c_planes: element (m, col) of the plane-carrying output into the three blocked bf16 planes (scalar form: split-K reducer)
+// (consecutive threads of the reducer own consecutive columns of a row -- N is even -- so lane ^ 1 holds the neighbouring column: dword stores)
 __device__ __forceinline__ void gemm_store_planes(const st_gemm_desc& d, int m, int col, float v) {
     __bf16 h, mi, lo;
     st_split3(v, h, mi, lo);
+    const unsigned ph = st_bf16_bits(h), pm = st_bf16_bits(mi), pl = st_bf16_bits(lo);
+    const unsigned nh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ph, 0xB1, 0xF, 0xF, false);
+    const unsigned nm = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0xB1, 0xF, 0xF, false);
+    const unsigned nl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pl, 0xB1, 0xF, 0xF, false);
+    if (col & 1) return;
     const int cc = d.c_plane_col0 + col;
-    __bf16* p = reinterpret_cast<__bf16*>(d.c_planes) + ((size_t)(cc >> 5) * d.c_plane_rows + d.c_plane_row0 + m) * 32 + (cc & 31);
-    p[0] = h; p[d.c_plane_stride] = mi; p[2 * d.c_plane_stride] = lo;
+    unsigned* p = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(d.c_planes) + ((size_t)(cc >> 5) * d.c_plane_rows + d.c_plane_row0 + m) * 32 + (cc & 31));
+    p[0] = ph | (nh << 16); p[d.c_plane_stride / 2] = pm | (nm << 16); p[d.c_plane_stride] = pl | (nl << 16);
 }
 
 // epilogue + store.  ST_EPI_ZR (fused GRU gates, gru.py:47-49): columns [0, N/2) are z -> C,
@@ -127,14 +133,19 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff,
 __device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, (int)soff, 0);
 }
-// st_gemm_desc.c_planes: the lane's value of accumulator row r into the three blocked bf16 planes: lanes li = 0..31 of a sub-tile are
-// the 32 channels of one chunk row, so a wave-instruction writes two 64-byte runs; the plane and the row step are SGPR offsets
-__device__ __forceinline__ void buf_st_planes(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned plane_b) {
+// st_gemm_desc.c_planes: the lane's value of accumulator row r into the three blocked bf16 planes.  Lanes li = 0..31 of a sub-tile are the 32
+// channels of one chunk row; neighbouring lanes exchange their halves (one DPP move per plane) and the EVEN lane stores the pair as a dword
+// (vp of the odd lanes is the out-of-range sentinel): 16 dword lanes = one 64-byte chunk row per wave half, no sub-dword store anywhere.
+__device__ __forceinline__ void buf_st_planes(float v, __amdgpu_buffer_rsrc_t r, unsigned vp_even, unsigned soff, unsigned plane_b) {
     __bf16 h, mi, lo;
     st_split3(v, h, mi, lo);
-    __builtin_amdgcn_raw_buffer_store_b16(st_bf16_bits(h), r, (int)voff, (int)soff, 0);
-    __builtin_amdgcn_raw_buffer_store_b16(st_bf16_bits(mi), r, (int)voff, (int)(soff + plane_b), 0);
-    __builtin_amdgcn_raw_buffer_store_b16(st_bf16_bits(lo), r, (int)voff, (int)(soff + 2u * plane_b), 0);
+    const unsigned ph = st_bf16_bits(h), pm = st_bf16_bits(mi), pl = st_bf16_bits(lo);
+    const unsigned nh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ph, 0xB1, 0xF, 0xF, false);     // quad_perm [1, 0, 3, 2]: lane ^ 1
+    const unsigned nm = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0xB1, 0xF, 0xF, false);
+    const unsigned nl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pl, 0xB1, 0xF, 0xF, false);
+    __builtin_amdgcn_raw_buffer_store_b32(ph | (nh << 16), r, (int)vp_even, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(pm | (nm << 16), r, (int)vp_even, (int)(soff + plane_b), 0);
+    __builtin_amdgcn_raw_buffer_store_b32(pl | (nl << 16), r, (int)vp_even, (int)(soff + 2u * plane_b), 0);
 }
 // row r of a lane's 16 accumulator registers, relative to the lane's first row
 #define ST_EPI_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
@@ -288,7 +299,9 @@ __device__ __forceinline__ void gemm_epilogue_store(const st_gemm_desc& d, float
             unsigned vp = ST_OOB;
             if (planes) {
                 const int pcol = d.c_plane_col0 + (zr ? n - half : n);
-                if (ncol && (!zr || n >= half) && row0 < d.M) vp = (unsigned)((((long long)(pcol >> 5) * d.c_plane_rows + prow0 + row0) * 32 + (pcol & 31)) * 2);
+                // (even lane: its column and the next are both inside -- the plane-carrying output has an even number of columns, host-checked)
+                if (!(li & 1) && ncol && (!zr || n >= half) && row0 < d.M)
+                    vp = (unsigned)((((long long)(pcol >> 5) * d.c_plane_rows + prow0 + row0) * 32 + (pcol & 31)) * 2);
             }
             if (zr) {
                 const unsigned vc = (ncol && n < half) ? (unsigned)(row0 * d.ldc + n) * 4u : ST_OOB;
@@ -656,9 +669,8 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
         }
     };
     set_mtile(m0);
-    // PERSIST walks plain matrices (rows are contiguous: set_rows) or convolutions (taps: set_mtile + set_tap at every M-tile change)
-    const bool pconv = PERSIST && !(d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.H * d.W == d.M &&
-                                    d.Ho * d.Wo == d.M);
+    // PERSIST walks plain matrices only (rows are contiguous: set_rows).  (Round 5 also let convolutions walk that way, re-deriving the tap
+    // addresses at every M-tile change: measured -1.9 % in the product, DESIGN.md section 5, and removed again in round 6 -- ADVICE r5.)
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int r = 8 * (wave * PB + i) + (lane >> 3);                    // row inside the B part; BM % 16 == 0
@@ -695,7 +707,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
             voffA[i] = (unsigned)(min(i_m0 + r, d.M - 1) * d.ldx + (((lane & 7) ^ ((r >> 1) & 7)) << 2)) * 4u;
         }
     };
-    if (PERSIST && !pconv) set_rows(); else set_tap();
+    if (PERSIST) set_rows(); else set_tap();
     auto issue_a = [&](int stage, int i) {
         lds_dma16(i_c0 < a2c ? rsrcA2 : rsrcA, lds0 + (unsigned)(stage * STAGE_FLOATS + (wave * PA + i) * 256) * 4u, voffA[i], soffA);
     };
@@ -707,14 +719,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const st_gemm_desc& d, const 
         if (PERSIST) {
             if (++i_kt == nkt) {
                 i_kt = 0; soffA = 0; soffB = 0; i_m0 += G * BM;
-                if (pconv) { i_c0 = 0; i_ky = 0; i_kx = 0; set_mtile(i_m0); set_tap(); } else set_rows();
-            } else if (pconv) {
-                i_c0 += 32;
-                if (i_c0 >= d.Cin) {
-                    i_c0 = 0; soffA = 0;
-                    if (++i_kx == d.kw) { i_kx = 0; ++i_ky; }
-                    set_tap();
-                }
+                set_rows();
             }
         } else {
             i_c0 += 32;
@@ -1752,16 +1757,14 @@ static int launch_dma(const st_gemm_desc& d, hipStream_t s) {
                        d.Ho * d.Wo == d.M;
     // Round-5 experiment, measured and NOT adopted (both switches default to the round-4 behaviour): ST_PERSIST_SLOTS=256 gives a launch ONE
     // workgroup slot per CU (a CU holds two of this LDS footprint; a workgroup then walks >= 2 M tiles with one continuous DMA ring) so that the
-    // second slot is left to the kernel of another stream, and ST_PERSIST_CONV=1 lets convolutions walk that way too (the kernel re-derives its
-    // per-lane tap addresses at every M-tile change).  On uniform GEMMs the idea pays (tools/persist_probe.py, 5 decoder shapes, one hipGraph
+    // second slot is left to the kernel of another stream (ST_PERSIST_CONV=1 also let convolutions walk that way; removed in round 6).  On uniform GEMMs the idea pays (tools/persist_probe.py, 5 decoder shapes, one hipGraph
     // per stream: 3 streams 120.9 -> 127.8 TFLOP/s, 2 streams 119.2 -> 124.1, 1 stream 104.2 -> 102.4); in the product it does not (bench.py,
     // 3 pairs in flight, same box, A/B/A: slots 512 conv 0: 82.66 / 82.58 pairs/s; 256 / 1: 81.09 / 80.67; 256 / 0: 82.60; 512 / 1: 82.22;
     // one pair in flight 72.4 -> 69.0): between the GEMMs of a forward run ~150 short kernels of other kinds, and a GEMM that holds one slot
     // runs at one wave per SIMD whenever the neighbouring stream is not in a GEMM itself.
     static const int slots_env = [] { const char* e = getenv("ST_PERSIST_SLOTS"); return e ? atoi(e) : 512; }();
-    static const int conv_persist = [] { const char* e = getenv("ST_PERSIST_CONV"); return e ? atoi(e) : 0; }();
     const int slots = slots_env / batch;
-    if (STAGES == 4 && (plain || (conv_persist && batch == 1)) && !d.a2 && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
+    if (STAGES == 4 && plain && !d.a2 && d.split_k <= 1 && (d.K / 32) % STAGES == 0 && (long)ntm * ntn > slots && ntn <= slots && slots > 0) {
         int G = slots / ntn;
         if (G > ntm) G = ntm;
         auto k = d.c_t ? conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true, true> : conv_gemm_dma_kernel<WM, WN, TM, TN, STAGES, true>;
@@ -1813,7 +1816,7 @@ static bool c_planes_ok(const st_gemm_desc& d) {
     if (!d.c_planes) return d.c_no_f32 == 0;
     const int batch = d.batch > 0 ? d.batch : 1;
     const int ncols = d.epi == ST_EPI_ZR ? d.N / 2 : d.N;
-    if ((d.M & 31) || (d.c_plane_col0 & 31) || d.c_plane_col0 < 0 || d.c_plane_row0 < 0 || d.c_plane_stride <= 0 || (d.c_plane_stride & 7) || d.c_plane_rows <= 0 ||
+    if ((d.M & 31) || (ncols & 1) || (d.c_plane_col0 & 31) || d.c_plane_col0 < 0 || d.c_plane_row0 < 0 || d.c_plane_stride <= 0 || (d.c_plane_stride & 7) || d.c_plane_rows <= 0 ||
         ((uintptr_t)d.c_planes & 15) || d.c_t)
         return false;
     const int64_t last_row = d.c_plane_row0 + (int64_t)(batch - 1) * d.c_plane_batch_rows + d.M;
@@ -2010,7 +2013,8 @@ static int launch_split3(const st_gemm_desc& d, hipStream_t s) {
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
     const int batch = d.batch > 0 ? d.batch : 1;
     const size_t lds = (size_t)STAGES * 3 * (BM + BN) * 64;
-    auto k = conv_gemm_split3_kernel<WM, WN, TM, TN, STAGES, DIAG>;
+    void (*k)(const st_gemm_desc) = conv_gemm_split3_kernel<WM, WN, TM, TN, STAGES, DIAG>;
+    if constexpr (TM * TN == 1 && WM == 2 && WN == 2 && STAGES == 3) k = conv_gemm_split3_kernel64<STAGES, DIAG>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(ntm * ntn, 1, d.split_k > 1 ? d.split_k : batch), dim3(512), lds, s, d);
     if (d.split_k > 1)
@@ -2030,6 +2034,7 @@ static int split3_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
     if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0 || d.reserved3 != 0 || d.c_t || d.a_ln) return ST_EINVAL;
     if (!c_planes_ok(d)) return ST_EINVAL;
+    if (d.split3 != 1) return ST_EINVAL;
     if (d.a_plane_stride <= 0 || d.w_plane_stride <= 0 || d.a_rows <= 0 || d.w_rows < d.N) return ST_EINVAL;
     if (((uintptr_t)d.a & 15) || ((uintptr_t)d.w & 15) || (d.a_plane_stride & 7) || (d.w_plane_stride & 7) || (d.batch_stride_a & 7) ||
         (d.batch_stride_w & 7))
@@ -2064,6 +2069,8 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
     // measured (tools/split3_probe.py, profiles/r6_split3_probe.json): 128x64 tiles on a 4-stage ring win when they still give every CU a
     // workgroup (N = 256 at M = 8 192: 41.8 vs 44.2 us), 64x64 tiles (two workgroups per CU) otherwise; 128x128 never
     if (cfg == 0) cfg = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * batch >= 256 ? 32 : 34;
+    static const int tile_env = [] { const char* e = getenv("ST_SPLIT3_TILE"); return e ? atoi(e) : 0; }();      // experiments: force one tile configuration
+    if (tile_env && d.tile_cfg == 0) cfg = tile_env;
     static const int bms[7] = {0, 128, 128, 64, 64, 128, 64}, bns[7] = {0, 128, 64, 128, 64, 64, 64};
     if (cfg < 31 || cfg > 36) return ST_EINVAL;
     const long tiles = (long)((d.M + bms[cfg - 30] - 1) / bms[cfg - 30]) * ((d.N + bns[cfg - 30] - 1) / bns[cfg - 30]) * batch;
@@ -2087,6 +2094,8 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
     // timing experiments (tools/split3_probe.py --diag): ST_SPLIT3_DIAG=1 consumers skip the MFMAs, 2 loaders skip the DMA; results are garbage
     static const int diag = [] { const char* e = getenv("ST_SPLIT3_DIAG"); return e ? atoi(e) : 0; }();
     if (diag == 1) return cfg == 34 ? launch_split3<2, 2, 1, 1, 3, 1>(d, s) : cfg == 32 ? launch_split3<2, 2, 2, 1, 4, 1>(d, s) : launch_split3<2, 2, 2, 2, 3, 1>(d, s);
+    if (diag == 3) return launch_split3<2, 2, 1, 1, 3, 3>(d, s);
+    if (diag == 4) return launch_split3<2, 2, 1, 1, 3, 4>(d, s);      // in-kernel clock stamps -> workspace (tools/split3_clock.py)
     if (diag == 2) return cfg == 34 ? launch_split3<2, 2, 1, 1, 3, 2>(d, s) : cfg == 32 ? launch_split3<2, 2, 2, 1, 4, 2>(d, s) : launch_split3<2, 2, 2, 2, 3, 2>(d, s);
     switch (cfg) {
         case 31: return launch_split3<2, 2, 2, 2, 3>(d, s);

@@ -83,6 +83,8 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
     const int kt0 = kz * per;
     const int ntiles = min(nkt_all, kt0 + per) - kt0;       // K steps of this workgroup (> 0: the host never over-splits)
 
+    unsigned long long sr_entry = 0;
+    if (DIAG == 4) sr_entry = __builtin_amdgcn_s_memrealtime();
     if (wave >= 4) {
         // ------------------------------------------------------------------ loader waves
         const int lw = wave - 4;
@@ -117,6 +119,8 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
             voffB[i] = (unsigned)plane * w_plane_b + (unsigned)min(n0 + r, d.N - 1) * 64u + (unsigned)c * 16u;
             ldsB[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(plane * PLANE_B + BM * 64 + rg * 1024));
         }
+        // (K steps ordered (tap, chunk) like the fp32 kernels.  The other order -- a chunk of A re-read for all its taps back to back, hoping for
+        // L1 / L2 hits -- was measured and is SLOWER: 1x5 conv 41.4 -> 48.4 us, 3x3 28.3 -> 34.3 us, tools/split3_probe.py of round 6.)
         int i_c0, i_ky, i_kx;
         {
             const int k = kt0 * 32, tap = k / d.Cin;
@@ -137,9 +141,9 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
             const unsigned so = (unsigned)(stage * STAGE_B);
             const bool second = i_c0 < a2c;
 #pragma unroll
-            for (int i = 0; i < PA; ++i) if (DIAG != 2) lds_dma16(second ? rsrcA2 : rsrcA, ldsA[i] + so, voffA[i], soffA);
+            for (int i = 0; i < PA; ++i) if (DIAG != 2 && DIAG != 3) lds_dma16(second ? rsrcA2 : rsrcA, ldsA[i] + so, voffA[i], soffA);
 #pragma unroll
-            for (int i = 0; i < PB; ++i) if (DIAG != 2) lds_dma16(rsrcW, ldsB[i] + so, voffB[i], soffB);
+            for (int i = 0; i < PB; ++i) if (DIAG != 2 && DIAG != 3) lds_dma16(rsrcW, ldsB[i] + so, voffB[i], soffB);
             soffB += w_chunk_b; soffA += a_chunk_b;
             i_c0 += 32;
             if (i_c0 >= d.Cin) {
@@ -156,11 +160,11 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
         };
         for (int t = 0; t < STAGES && t < ntiles; ++t) issue_tile(t);
         wait_tiles(min(STAGES - 1, ntiles - 1));    // tile 0 has landed (this wave's pieces) ...
-        asm volatile("s_barrier" ::: "memory");     // ... and everybody else's
+        if (DIAG != 3) asm volatile("s_barrier" ::: "memory");     // ... and everybody else's
         int stage = 0;
         for (int t = 0; t + 1 < ntiles; ++t) {
             wait_tiles(min(STAGES - 2, ntiles - 2 - t));   // tile t+1 landed; tiles t+2 .. t+STAGES-1 may still fly
-            asm volatile("s_barrier" ::: "memory"); // consumers have every fragment of tile t in registers: its stage is free
+            if (DIAG != 3) asm volatile("s_barrier" ::: "memory"); // consumers have every fragment of tile t in registers: its stage is free
             if (t + STAGES < ntiles) issue_tile(stage);
             stage = stage == STAGES - 1 ? 0 : stage + 1;
         }
@@ -190,6 +194,9 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
         pa[j] = sm + (wm * TM * 32 + li) * 64 + ch * 16;
         pb[j] = sm + (BM + wn * TN * 32 + li) * 64 + ch * 16;
     }
+    // (Measured and dropped, round 6, 1x5 conv 8192 x 256 x 1920 on 64x64 tiles: a third fragment buffer so that both 16-k steps of the next
+    // tile are requested right behind the barrier -- 44.5 us either way; two alternating accumulators per sub-tile -- 33.1 vs 33.6 us MFMA-only;
+    // no barriers at all, MFMA-only -- 33.6 us: the consumer side is MFMA-bound at ~90 % while its workgroup runs, tools/split3_clock.py.)
     bf16x8 fa[2][3][TM], fb[2][3][TN];
     // One product = TM x TN MFMAs on one (A plane, B plane) pair.  The fragment reads of the NEXT 16-k step ride in the gaps between the
     // MFMAs of the first three products, one or two ds_read_b128 per gap (a burst of 12 reads between two MFMAs drains the matrix pipe:
@@ -204,8 +211,8 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
-                if (DIAG != 1) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][p][i], fb[buf][q][jn], acc[i][jn], 0, 0, 0);
-                else asm volatile("" ::"v"(fa[buf][p][i]), "v"(fb[buf][q][jn]));       // keep the fragment reads alive
+                if (DIAG == 1) asm volatile("" ::"v"(fa[buf][p][i]), "v"(fb[buf][q][jn]));       // keep the fragment reads alive
+                else acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][p][i], fb[buf][q][jn], acc[i][jn], 0, 0, 0);
                 if (set >= 0) {
                     const int upto = ((i * TN + jn + 1) * NR + NM - 1) / NM;           // reads due after this MFMA
 #pragma unroll
@@ -227,10 +234,18 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
         for (int r = 0; r < TN; ++r) fb[nbuf][rb][r] = *reinterpret_cast<const bf16x8*>(pb[nj] + nstage * STAGE_B + rb * PLANE_B + r * 2048);
     };
 
-    // (epilogue operands are fetched AFTER the K loop: ahead of it, a 64x64 wave tile's 3 x 64 operand registers would have to live
-    // beside 128 accumulator + 96 fragment registers at two waves per SIMD)
+    // Epilogue operands: fetched AHEAD of the K loop when the wave owns one sub-tile (48 registers; issued after it they are two or three
+    // dependent L2 round trips with nothing to hide them: all workgroups of a launch finish together); for larger wave tiles AFTER it
+    // (3 x 64 operand registers would have to live beside 128 accumulator + 96 fragment registers at two waves per SIMD).
+    constexpr bool EPI_AHEAD = false;     // (48 more registers would push the 64x64 configuration past 128: one workgroup per CU instead of two)
+    EpiOperands<TM, TN> eop;
+    if (EPI_AHEAD) {
+        gemm_epilogue_consts<TM, TN>(d, eop, n0, wn, li, split);
+        gemm_epilogue_load<TM, TN>(d, eop, m0, n0, wm, wn, li, lh, split);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
-    asm volatile("s_barrier" ::: "memory");         // tile 0 is in LDS
+    if (DIAG != 3) asm volatile("s_barrier" ::: "memory");         // tile 0 is in LDS
     read_set(0, 0, 0, 0); read_set(0, 0, 0, 1); read_set(0, 0, 0, 2);
     __builtin_amdgcn_sched_barrier(0);
     // MORE (a literal in the steady state): tile t+1 exists.  Kept out of a run-time branch there: behind a branch that only sometimes
@@ -244,7 +259,7 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
         // 16-k step 1 (buffer 1)
         if (MORE || more_rt) {
             // every read of stage s has returned (lgkmcnt(0)); tile t+1 has landed everywhere; the loaders may now refill stage s
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (DIAG != 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             prod(1, 2, 0, 0, (s + 1) % STAGES, 0, 0); prod(1, 0, 2, 0, (s + 1) % STAGES, 0, 1); prod(1, 1, 1, 0, (s + 1) % STAGES, 0, 2);
         } else {
             prod(1, 2, 0, 0, 0, 0, -1); prod(1, 0, 2, 0, 0, 0, -1); prod(1, 1, 1, 0, 0, 0, -1);
@@ -262,6 +277,8 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    unsigned long long st0 = 0, sr0 = 0;
+    if (DIAG == 4) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
     int tb = 0;
     for (; tb + STAGES < ntiles; tb += STAGES) {     // every tile of the turn has a successor
 #pragma unroll
@@ -270,23 +287,38 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
 #pragma unroll
     for (int s = 0; s < STAGES; ++s)
         if (tb + s < ntiles) tile_body(st_false{}, s, tb + s, tb + s + 1 < ntiles);
+    if (DIAG == 4 && wave == 0 && lane == 0 && d.workspace) {      // in-kernel clock of the K loop: shader cycles per 100 MHz tick (diagnostic build only)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(d.workspace) + (size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8;
+        const unsigned long long sr1 = __builtin_amdgcn_s_memrealtime();
+        o[0] = __builtin_amdgcn_s_memtime() - st0; o[1] = sr1 - sr0; o[2] = sr_entry; o[3] = sr0; o[4] = sr1;
+    }
     if (ntiles > KBLK) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] + tot[i][j];
     }
-    gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
+    if (EPI_AHEAD) gemm_epilogue_store<TM, TN, false, false>(d, C, acc, eop, m0, n0, wm, wn, li, lh, split, kz);
+    else gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
+    if (DIAG == 4 && wave == 0 && lane == 0 && d.workspace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        reinterpret_cast<unsigned long long*>(d.workspace)[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 template <int WM, int WN, int TM, int TN, int STAGES, int DIAG = 0>
 __global__ __launch_bounds__(512) void conv_gemm_split3_kernel(const st_gemm_desc d) {
     conv_gemm_split3_body<WM, WN, TM, TN, STAGES, DIAG>(d, (int)blockIdx.x);
 }
+// the 64x64 configuration lives on TWO workgroups per CU (72 KB of LDS each): 4 waves per SIMD, so at most 128 registers per wave
+template <int STAGES, int DIAG = 0>
+__global__ __launch_bounds__(512, 4) void conv_gemm_split3_kernel64(const st_gemm_desc d) {
+    conv_gemm_split3_body<2, 2, 1, 1, STAGES, DIAG>(d, (int)blockIdx.x);
+}
 
 // two independent split3 contractions in one launch (st_conv_gemm_pair with split3 descriptors): workgroups [0, tiles0) run d[0], the rest d[1]
 template <int WM, int WN, int TM, int TN, int STAGES>
-__global__ __launch_bounds__(512) void conv_gemm_split3_pair_kernel(const st_gemm_pair_args g) {
+__global__ __launch_bounds__(512, 4) void conv_gemm_split3_pair_kernel(const st_gemm_pair_args g) {
     const bool second = (int)blockIdx.x >= g.tiles0;             // workgroup-uniform
     conv_gemm_split3_body<WM, WN, TM, TN, STAGES, 0>(second ? g.d[1] : g.d[0], second ? (int)blockIdx.x - g.tiles0 : (int)blockIdx.x);
 }

@@ -47,6 +47,8 @@ FORK_ENC = os.environ.get("ST_FORK_ENC", "0") == "1"           # experiment: flo
 SPLIT3 = os.environ.get("ST_SPLIT3", "1") != "0"
 FUSE_PE = os.environ.get("ST_FUSE_PE", "1") != "0"              # PatchEmbed c0 + c2 per cost map in one launch (csrc/patchembed.hip; the library reads the same switch)
 assert not (SPLIT3 and FORK_ENC), "ST_FORK_ENC is an fp32-path experiment"
+S3_PAIR = os.environ.get("ST_S3_PAIR", "1") != "0"
+S3_OFF = int(os.environ.get("ST_S3_OFF", "0"))     # bisecting aid: bit 1 mask-head conv, 2 flow-head conv, 4 aggregate, 8 GRU, 16 motion conv, 32 conv pair back on the fp32 kernels
 _SIDE = {}
 
 
@@ -547,14 +549,36 @@ class FlowFormer(ParamTree):
             # convc1 (K = 160) stays on the fp32 kernel and emits cor1's planes; flow_encode emits flo1's and the flow's two channels
             ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu", out_planes=S["cor1_p"])
             ops.flow_encode_split3(coords1, D["convf1"][0], D["convf1"][1], S["flo1"], hxA[:, 254:256], B, H1, W1, S["flo1_p"], (hxA_p, 254))
-            ops.conv_gemm_pair((S["cor1_p"], W3["convc2"], S["corflo"][:, :192],
-                                dict(geom=g3, bias=D["convc2"][1], act="relu", out_planes=S["corflo_p"].cols(0, 192), no_f32=True)),
-                               (S["flo1_p"], W3["convf2"], S["corflo"][:, 192:],
-                                dict(geom=g3, bias=D["convf2"][1], act="relu", out_planes=S["corflo_p"].cols(192, 256), no_f32=True)))
-            ops.conv_gemm(S["corflo_p"], W3["conv"], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu", out_planes=hxA_p.cols(128, 256))
-            ops.gma_aggregate_split3(attn, hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], S["vT_p"], hxA[:, 256:], hxA_p.cols(256, 384), B, N)
-            ops.sepconv_gru_split3(hxA, hxA_p, S["hxB_p"], S["zbuf"], gru_tab["1"], gru_tab["2"], W3["zr1"], W3["q1"], W3["zr2"], W3["q2"], B, H1, W1)
-            ops.conv_gemm(hxA_p.cols(0, 128), W3["fh1"], S["fh"], geom=g3, bias=D["fh1"][1], act="relu")
+            nf = not (S3_OFF & 16)
+            if S3_OFF & 32:
+                ops.conv_gemm_pair((S["cor1"], D["convc2"][0], S["corflo"][:, :192], dict(geom=g3, bias=D["convc2"][1], act="relu", out_planes=S["corflo_p"].cols(0, 192))),
+                                   (S["flo1"], D["convf2"][0], S["corflo"][:, 192:], dict(geom=g3, bias=D["convf2"][1], act="relu", out_planes=S["corflo_p"].cols(192, 256))))
+            elif not S3_PAIR:
+                ops.conv_gemm(S["cor1_p"], W3["convc2"], S["corflo"][:, :192], geom=g3, bias=D["convc2"][1], act="relu", out_planes=S["corflo_p"].cols(0, 192), no_f32=nf)
+                ops.conv_gemm(S["flo1_p"], W3["convf2"], S["corflo"][:, 192:], geom=g3, bias=D["convf2"][1], act="relu", out_planes=S["corflo_p"].cols(192, 256), no_f32=nf)
+            else:
+                ops.conv_gemm_pair((S["cor1_p"], W3["convc2"], S["corflo"][:, :192],
+                                    dict(geom=g3, bias=D["convc2"][1], act="relu", out_planes=S["corflo_p"].cols(0, 192), no_f32=nf)),
+                                   (S["flo1_p"], W3["convf2"], S["corflo"][:, 192:],
+                                    dict(geom=g3, bias=D["convf2"][1], act="relu", out_planes=S["corflo_p"].cols(192, 256), no_f32=nf)))
+            if S3_OFF & 16:
+                ops.conv_gemm(S["corflo"], D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu", out_planes=hxA_p.cols(128, 256))
+            else:
+                ops.conv_gemm(S["corflo_p"], W3["conv"], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu", out_planes=hxA_p.cols(128, 256))
+            if S3_OFF & 4:
+                ops.gma_aggregate(S["attn_f32"], hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], hxA[:, 256:], B, N)
+                ops.split3_pack(hxA[:, 256:], out=hxA_p.cols(256, 384))
+            else:
+                ops.gma_aggregate_split3(attn, hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], S["vT_p"], hxA[:, 256:], hxA_p.cols(256, 384), B, N)
+            if S3_OFF & 8:
+                ops.sepconv_gru(hxA, hxB, S["zbuf"], gru_tab["1"], gru_tab["2"], D["zr1"], D["q1"], D["zr2"], D["q2"], B, H1, W1)
+                ops.split3_pack(hxA[:, :128], out=hxA_p.cols(0, 128))
+            else:
+                ops.sepconv_gru_split3(hxA, hxA_p, S["hxB_p"], S["zbuf"], gru_tab["1"], gru_tab["2"], W3["zr1"], W3["q1"], W3["zr2"], W3["q2"], B, H1, W1)
+            if S3_OFF & 2:
+                ops.conv_gemm(hxA[:, :128], D["fh1"][0], S["fh"], geom=g3, bias=D["fh1"][1], act="relu")
+            else:
+                ops.conv_gemm(hxA_p.cols(0, 128), W3["fh1"], S["fh"], geom=g3, bias=D["fh1"][1], act="relu")
             ops.conv_gemm(S["fh"], D["fh2"][0], coords1, geom=g3, bias=D["fh2"][1], epi="add", aux1=coords1)
             return
         ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu")
@@ -581,7 +605,7 @@ class FlowFormer(ParamTree):
     def _mask_head(self, S, B, H1, W1):
         """mask = .25 * conv1x1(relu(conv3x3(net))) (gru.py:315-318,333) -> rows [R, 576]."""
         D = self._pk["dec"]
-        if S["s3"]:
+        if S["s3"] and not (S3_OFF & 1):
             ops.conv_gemm(S["hxA_p"].cols(0, 128), D["s3"]["m0"], S["fh"], geom=(B, H1, W1, 3, 3, 1, 1, 1, 1), bias=D["m0"][1], act="relu")
         else:
             ops.conv_gemm(S["hxA"][:, :128], D["m0"][0], S["fh"], geom=(B, H1, W1, 3, 3, 1, 1, 1, 1), bias=D["m0"][1], act="relu")
@@ -606,6 +630,8 @@ class FlowFormer(ParamTree):
         attn = torch.empty((B, N, N), device=dev)
         ops.gma_attention(inp, D["qk"], qk, attn, B, N)
         if S["s3"]:                # the attention matrix is read 12 times as a contraction operand: its planes, once per pass
+            if S3_OFF & 4:
+                S["attn_f32"] = attn
             attn = ops.split3_pack(attn.view(B * N, N))
         return dict(S=S, inp=inp, gru_tab=gru_tab, attn=attn, qk=qk)
 

@@ -445,9 +445,19 @@ def cost_lookup9x9(maps, coords, out, Nq, H2, W2):
 
 
 def patch_embed(cost_maps, weights11, ld_f0, pe_bias, s1, s2, s3, s4, tokens, M, H, W):
+    """s1 = None: the caller expects the fused c0 + c2 launch (64 x 64 maps).  Whether it fuses is the LIBRARY's decision (its own reading of
+    ST_FUSE_PE, operand alignment): if it declines (ST_EINVAL) the scratch is allocated here and the call repeated -- the two sides cannot
+    disagree into a hard failure."""
     arr = (C.c_void_p * 11)(*[w.data_ptr() for w in weights11])
-    check(lib.st_patch_embed(_pc(cost_maps), arr, ld_f0, _pc(pe_bias), _pc(s1) if s1 is not None else None, _pc(s2), _pc(s3), _pc(s4), _pc(tokens),
-                             M, H, W, *_ws(cost_maps.device), _stream()), "st_patch_embed")
+
+    def call(s1_):
+        return lib.st_patch_embed(_pc(cost_maps), arr, ld_f0, _pc(pe_bias), _pc(s1_) if s1_ is not None else None, _pc(s2), _pc(s3), _pc(s4), _pc(tokens),
+                                  M, H, W, *_ws(cost_maps.device), _stream())
+    rc = call(s1)
+    if rc == 1001 and s1 is None:
+        Hp, Wp = (H + 7) // 8 * 8, (W + 7) // 8 * 8
+        rc = call(torch.empty((M * (Hp // 2) * (Wp // 2), 16), device=cost_maps.device, dtype=torch.float32))
+    check(rc, "st_patch_embed")
     return tokens
 
 
@@ -538,9 +548,10 @@ def flow_warp(x, flow, mul=None):
     return out
 
 
-def resize_bilinear(x, oh, ow, align_corners, div=None):
+def resize_bilinear(x, oh, ow, align_corners, div=None, out=None):
     B, Cc, H, W = x.shape
-    out = torch.empty((B, Cc, oh, ow), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, Cc, oh, ow), device=x.device, dtype=torch.float32)
     d0, d1, nd = (div[0], div[1], 2) if div is not None else (1.0, 1.0, 0)
     check(lib.st_resize_bilinear(_pc(x), _p(out), B * Cc, H, W, oh, ow, int(align_corners), d0, d1, nd, _stream()),
           "st_resize_bilinear")

@@ -9,11 +9,12 @@ _REC = {}
 _OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_measured.json")
 
 
-def check(name, value, bound, inclusive=False):
+def check(name, value, bound, inclusive=False, note=""):
+    """``note``: what the bound was derived from (e.g. the reference's own spread on the same case), quoted in the failure message."""
     value, bound = float(value), float(bound)
-    _REC[name] = dict(measured=value, bound=bound)
+    _REC[name] = dict(measured=value, bound=bound, **({"note": note} if note else {}))
     ok = value <= bound if inclusive else value < bound
-    assert ok, f"{name}: measured {value:.4g} exceeds the bound {bound:.4g}"
+    assert ok, f"{name}: measured {value:.4g} exceeds the bound {bound:.4g}" + (f" [{note}]" if note else "")
     return value
 
 

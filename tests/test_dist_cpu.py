@@ -158,7 +158,11 @@ def test_peer_of_a_dead_rank_times_out_without_a_launcher(tmp_path):
     out of the collective (peer closed / the finite `dist.timeout()` every process group here is opened with) instead of waiting forever."""
     script = tmp_path / "guard_worker.py"
     script.write_text(GUARD_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2", ST_DIST_TIMEOUT_S="20")
+    import socket
+    with socket.socket() as sk:                       # a free port (a busy fixed one would turn this into a false failure or a 200 s timeout)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", ST_DIST_TIMEOUT_S="20")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=200)[0].decode() for p in procs]

@@ -139,10 +139,15 @@ def test_graphs_are_recaptured_when_the_weights_change_identity(tmp_path, model,
         with torch.no_grad():
             w = next(p for n, p in model.homo_backbone.named_parameters() if p.ndim == 4)
             w.mul_(1.01)
-        model.homo_backbone._invalidate()                                           # the packed copy is the caller's to refresh after a raw write
+        # (no manual _invalidate(): the deep check drops the backbones' packed copies itself -- ADVICE r5)
         _, tab_p2 = ev.validate_with_model(model, ds, streams=2)
+        assert not torch.equal(tab_p2, tab_p), "the harness still computes with the weights packed before the in-place write"
+        model.homo_backbone._invalidate(); model.flow_backbone._invalidate()       # the reference: eager run on freshly packed weights
         _, tab_e2 = ev.validate_with_model(model, ds, pipelined=False)
         assert torch.equal(tab_p2, tab_e2)
+        o = g(a, b)                                                                 # the shallow holders re-capture too (the generation moved)
+        ref2 = model(a, b, type="test_eval")
+        assert torch.equal(o["final_warp_output"], ref2["final_warp_output"]) and not torch.equal(ref2["final_warp_output"], ref["final_warp_output"])
     finally:
         model.load_state_dict(seeded_sd, strict=True)
     _, tab_back = ev.validate_with_model(model, ds, streams=2)

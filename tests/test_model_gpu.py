@@ -156,6 +156,8 @@ def test_update_block_vs_reference_golden(model, golden_ops):
     assert (attn.cpu() - ref_attn).abs().max() < 2e-6, (attn.cpu() - ref_attn).abs().max()      # softmax rows, values <= 1
     S = fb._update_state(R, B, N, torch.device("cuda"))
     S["hxA"][:, :128] = rows(T(g["ub_net"]))
+    if S.get("s3"):               # split3 path: the state also lives as bf16 planes (written by proj_net's / the q convs' epilogues in a forward)
+        ops.split3_pack(S["hxA"][:, :128], out=S["hxA_p"].cols(0, 128))
     corr = T(g["ub_corr"])                                     # reference order: cat([cost_global 64, cost_forward 81])
     S["corr"][:, :81] = rows(corr[:, 64:])
     S["corr"][:, 84:148] = rows(corr[:, :64])
@@ -336,11 +338,17 @@ def test_end_to_end_reference_demo_pairs_512(model, name):
     # test_demo_pairs_damped_vs_reference_golden_and_floor.
     fl = np.load(os.path.join(GOLDEN, "e2e_r5_512.npz"))
     F = lambda k: max(float(fl[f"{name}_floor_seeded_eval_{k}"]), float(fl[f"{name}_seeded_floor_avx2_{k}"]))          # noqa: E731
-    check(f"{name}_eval_flow_max_px", dflow.max(), min({"demo1": 0.23, "demo2": 0.055}[name], 3 * F("flow_max_px")))      # measured 0.076 / 0.018 (demo1 / demo2)
-    check(f"{name}_eval_flow_p99_px", np.percentile(dflow, 99), min({"demo1": 0.054, "demo2": 0.017}[name], 3 * F("flow_p99_px")))      # measured 0.018 / 0.0055
-    check(f"{name}_eval_output_H_p99", np.percentile(np.abs(o["output_H"][..., ::8, ::8].cpu().numpy() - g[p + "output_H_sub"]), 99), min({"demo1": 1.2e-2, "demo2": 8.4e-3}[name], 3 * F("output_H_p99")))      # measured 4.1e-3 / 2.8e-3
-    check(f"{name}_eval_occ_flips", np.unpackbits(_bits(o["origin_occlusion_mask"]) ^ g[p + "occ_bits"]).sum(), min({"demo1": 2400, "demo2": 1370}[name], 3 * F("occ_flips")))      # measured 785 / 457
-    check(f"{name}_eval_overlap_flips", np.unpackbits(_bits(o["overlap"]) ^ g[p + "overlap_bits"]).sum(), min({"demo1": 15, "demo2": 3}[name], max(3, 3 * F("overlap_flips"))), inclusive=True)      # measured 5 / 1
+
+    def why(k):        # the reference's own spread on THIS quantity of THIS pair, quoted when a bound trips
+        return (f"seeded (chaotic) weights amplify a last-bit difference ~1e4x: the reference against ITSELF on this pair moves {k} by "
+                f"{float(fl[f'{name}_floor_seeded_eval_{k}']):.4g} (8 vs 1 CPU threads) and {float(fl[f'{name}_seeded_floor_avx2_{k}']):.4g} (AVX2 vs AVX-512 MKL); "
+                f"bound = min(3x that floor, 3x this build's first measurement).  The gate for a change of summation order is the damped-weights "
+                f"test (test_demo_pairs_damped_vs_reference_golden_and_floor: flow 2.1e-4 px, <= 4 flips)")
+    check(f"{name}_eval_flow_max_px", dflow.max(), min({"demo1": 0.23, "demo2": 0.055}[name], 3 * F("flow_max_px")), note=why("flow_max_px"))      # measured 0.076 / 0.018 (demo1 / demo2)
+    check(f"{name}_eval_flow_p99_px", np.percentile(dflow, 99), min({"demo1": 0.054, "demo2": 0.017}[name], 3 * F("flow_p99_px")), note=why("flow_p99_px"))      # measured 0.018 / 0.0055
+    check(f"{name}_eval_output_H_p99", np.percentile(np.abs(o["output_H"][..., ::8, ::8].cpu().numpy() - g[p + "output_H_sub"]), 99), min({"demo1": 1.2e-2, "demo2": 8.4e-3}[name], 3 * F("output_H_p99")), note=why("output_H_p99"))      # measured 4.1e-3 / 2.8e-3
+    check(f"{name}_eval_occ_flips", np.unpackbits(_bits(o["origin_occlusion_mask"]) ^ g[p + "occ_bits"]).sum(), min({"demo1": 2400, "demo2": 1370}[name], 3 * F("occ_flips")), note=why("occ_flips"))      # measured 785 / 457
+    check(f"{name}_eval_overlap_flips", np.unpackbits(_bits(o["overlap"]) ^ g[p + "overlap_bits"]).sum(), min({"demo1": 15, "demo2": 3}[name], max(3, 3 * F("overlap_flips"))), inclusive=True, note=why("overlap_flips"))      # measured 5 / 1
     o = model(a, b, type="test_out")
     p = name + "_out_"
     assert [o["width_min"], o["height_min"], o["out_height"], o["out_width"]] == list(g[p + "ints"])      # canvas ints exact
@@ -503,3 +511,19 @@ def test_graphed_test_out_matches_eager(model):
             assert [o[k] for k in ("width_min", "height_min", "out_height", "out_width")] == [e[k] for k in ("width_min", "height_min", "out_height", "out_width")]
             for k in ("blend_image", "output2", "mask2", "residual_flow", "occlusion_mask", "H"):
                 assert torch.equal(e[k], o[k]), k
+
+
+def test_forward_accepts_cpu_input_tensors(model):
+    """The reference's callers hand `forward` whatever the loader produced -- CPU float tensors through nn.DataParallel (out.py:80,197,
+    evaluate.py:43,119).  The drop-in moves them to the module's device like DataParallel's scatter; the result is the
+    result of the same call on device tensors, bit for bit."""
+    a, b = inputs.structured_pair(304, 400, seed=91, shift=(2, -3))
+    assert not a.is_cuda
+    ref = model(a.cuda(), b.cuda(), type="test_out")
+    got = model(a, b, type="test_out")                       # out.py:197's call shape
+    for k in ("blend_image", "output2", "mask2", "residual_flow", "H"):
+        assert got[k].is_cuda and torch.equal(got[k], ref[k]), k
+    assert [got[k] for k in ("width_min", "height_min", "out_height", "out_width")] == [ref[k] for k in ("width_min", "height_min", "out_height", "out_width")]
+    a5, b5 = inputs.structured_pair(512, 512, seed=92)
+    e_ref, e_got = model(a5.cuda(), b5.cuda(), type="test_eval"), model(a5, b5, type="test_eval")      # evaluate.py:43
+    assert torch.equal(e_got["final_warp_output"], e_ref["final_warp_output"]) and torch.equal(e_got["H"], e_ref["H"])

@@ -465,6 +465,29 @@ def test_tps(ops, golden_ops):
     check("tps_out_p99", np.percentile(d.numpy(), 99), ref_floor_p99)
 
 
+def test_tps_on_a_photograph(ops):
+    """a-18 on IMAGE CONTENT: the UDIS2 TPS transformer (torch_tps_transform.py:7-190) of the reference's own demo photograph
+    (demo/demo1/input1.jpg, 512 x 512) through its 169-point mesh with a smooth <= 3 px perturbation, against the reference's output
+    (tests/golden/tps_photo_512.npz, oracle/ref_harness/make_r6_goldens.py).  The noise-image case above bounds the worst case (gradient 255 grey
+    levels / px: 0.0265); this one says what "warped-pixel L-inf" is on a photograph.  Floor = the reference against itself under AVX2 / SSE4.2 MKL
+    on the same input: max 0.0148 / 0.0186, p99 0.0029 / 0.0030 grey levels."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "tps_photo_512.npz"))
+    img = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_demo_512.npz"))["demo1_input1"]
+    U = T(img).permute(2, 0, 1).float()[None].contiguous()
+    src, tgt = T(G["photo_source"]), T(G["photo_target"])
+    out, Tm, _ = ops.tps_transform(dev(U), dev(src), dev(tgt), (512, 512), want_idx=True)
+    relT = (Tm.cpu() - T(G["photo_T"])).abs().max().item() / max(1.0, float(np.abs(G["photo_T"]).max()))
+    check("tps_photo_T_rel", relT, 1e-6)
+    d = (out.cpu()[..., ::4, ::4] - T(G["photo_out_sub"])).abs().numpy()
+    fl_max = min(float(G["floor_avx2_photo_out_max"]), float(G["floor_sse4_2_photo_out_max"]))
+    fl_p99 = min(float(G["floor_avx2_photo_out_p99"]), float(G["floor_sse4_2_photo_out_p99"]))
+    print(f"[tps photo] |out - reference| max {d.max():.3e} p99 {np.percentile(d, 99):.3e} grey levels of 0..255 (reference's own host-to-host floor: "
+          f"max {fl_max:.3e} p99 {fl_p99:.3e}; the CPU oracle with the correctly rounded log: {float(G['oracle_vs_reference_out_max']):.3e}); T rel {relT:.2e}")
+    check("tps_photo_out_max_grey_levels", d.max(), fl_max)
+    check("tps_photo_out_p99_grey_levels", np.percentile(d, 99), fl_p99)
+    check("tps_photo_out_sum_rel", abs(out.double().sum().item() - float(G["photo_out_sum"])) / float(G["photo_out_sum"]), 1e-7)
+
+
 def test_blend_and_eval_finish(ops):
     """Mask algebra + uint8 blend (flowHomoAdpater.py:339-360): every intermediate is one fp32 rounding per torch op in
     the reference, and the kernel keeps exactly those roundings (no contraction): outputs are BIT-EXACT, including the

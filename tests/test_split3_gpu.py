@@ -238,3 +238,29 @@ def test_split3_rejects_what_it_cannot_run(ops):
         ops.conv_gemm(xp, wp, out, tile=13)                   # an fp32-kernel tile
     with pytest.raises(ops.StitchErrorBase):                      # planes of a result whose rows are not whole 32-row tiles
         ops.conv_gemm(dev(torch.randn(40, 64)), dev(torch.randn(32, 64)), torch.empty(40, 32, device="cuda"), out_planes=ops.Planes(40, 32, "cuda"))
+
+
+def test_split3_kernels_do_not_corrupt_their_neighbours(ops):
+    """Round-6 finding (tools/neighbour_stress.py): beside waves that issue bf16 MFMAs back to back, packed-fp32 VALU instructions of OTHER
+    waves returned wrong lanes 48-63 (the path's bilinear resize, run on a second stream beside a split3 GEMM, was wrong in 80 % of its
+    launches).  The library is therefore built without packed-fp32 instructions (build.py); this guards the build flag."""
+    g0 = g(50)
+    B, H, W, Cin, N = 2, 64, 64, 256, 192
+    x, w = dev(torch.randn(B * H * W, Cin, generator=g0)), dev(torch.randn(N, 9 * Cin, generator=g0) / 48)
+    xp, wp = ops.split3_pack(x), ops.split3_pack(w)
+    out = torch.empty(B * H * W, N, device="cuda")
+    flow = dev(torch.randn(2, 2, 512, 512, generator=g0) * 5)
+    ref = ops.resize_bilinear(flow, 320, 416, True, div=(512 / 416.0, 512 / 320.0)).clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ws = ops.new_workspace(torch.device("cuda"))
+    bad = 0
+    for _ in range(40):
+        with torch.cuda.stream(sb), ops.workspace_scope(ws):
+            for _ in range(12):
+                ops.conv_gemm(xp, wp, out, geom=(B, H, W, 3, 3, 1, 1, 1, 1), act="relu")
+        with torch.cuda.stream(sa):
+            rs = [ops.resize_bilinear(flow, 320, 416, True, div=(512 / 416.0, 512 / 320.0)) for _ in range(12)]
+        torch.cuda.synchronize()
+        bad += sum(not torch.equal(r, ref) for r in rs)
+    assert bad == 0, f"{bad} of 480 resize launches beside a split3 GEMM were corrupted"

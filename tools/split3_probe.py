@@ -197,7 +197,9 @@ def main():
     makers = dict(conv1x5=conv(256, 384, 1, 5), aggregate=aggregate, corr=corr,
                   # the other decoder convolutions of one refinement iteration (gru.py:44-59,246-254,5-13), M = 8 192
                   zr5x1=conv(256, 384, 5, 1), q1x5=conv(128, 384, 1, 5), convc2=conv(192, 256, 3, 3), convf2=conv(64, 128, 3, 3),
-                  conv3x3=conv(126, 256, 3, 3), fh1=conv(256, 128, 3, 3))
+                  conv3x3=conv(126, 256, 3, 3), fh1=conv(256, 128, 3, 3),
+                  # duration vs K at fixed M x N (fixed cost per launch / in-loop rate): 1x5 conv, Cin = 32 .. 768
+                  k160=conv(256, 32, 1, 5), k640=conv(256, 128, 1, 5), k3840=conv(256, 768, 1, 5))
     results = []
     for name in a.shapes.split(","):
         results.append(run_shape(name, makers[name], a.iters, tiles))
