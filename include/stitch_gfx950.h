@@ -251,6 +251,10 @@ int st_patch_conv1(const float* maps, const float* w36x16, const float* bias, fl
  * the unfused launches).                                                                              */
 int st_patch_conv12(const float* cost_maps, const float* c0_w36x16, const float* c0_b, const float* c2_w32x576,
                     const float* c2_b, float* s2, int32_t M, int32_t H, int32_t W, void* stream);
+/* st_patch_conv12 whose result leaves as three blocked bf16 planes [1 chunk][M*256 rows][32] (s2_pstride elements apart) instead of fp32 rows:
+ * the operand of the split3 form of PatchEmbed's third convolution (st_patch_embed_split3).  encoder.py:60-75.                    */
+int st_patch_conv12_planes(const float* cost_maps, const float* c0_w36x16, const float* c0_b, const float* c2_w32x576, const float* c2_b,
+                           void* s2_planes, int64_t s2_pstride, int32_t M, int32_t H, int32_t W, void* stream);
 int st_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t rows, int32_t cols, void* stream);
 /* NCHW image -> channels-last rows with v = mul*(x/div) - sub (flowHomoAdpater.py:55-56,
  * transformer.py:53-54); channels C..ldo-1 are zero.                                               */
@@ -369,6 +373,12 @@ int st_morph_open19(const float* mask, float* out, void* scratch_u8x2, int32_t N
 int st_patch_embed(const float* cost_maps, const float* const* weights, int32_t ld_f0, const float* pe_bias,
                    float* s1, float* s2, float* s3, float* s4, float* tokens, int32_t M, int32_t H, int32_t W,
                    void* workspace, int64_t workspace_floats, void* stream);
+/* st_patch_embed for 64 x 64 maps with Conv2d(32, 64, 6, 2, 2) -- 77 of the operator's 99 GFLOP per pair -- on exact-split operands
+ * (st_gemm_desc.split3): s2_planes scratch [3][1][M*256][32] written by the fused c0 + c2 launch, c4_w_planes = st_split3_pack(c4_w [64, 1152]).
+ * M <= 16 384 maps per call (2 GiB buffer offsets).  encoder.py:60-95.                                                              */
+int st_patch_embed_split3(const float* cost_maps, const float* const* weights, int32_t ld_f0, const float* pe_bias, void* s2_planes,
+                          int64_t s2_pstride, const void* c4_w_planes, int64_t c4_w_pstride, float* s3, float* s4, float* tokens, int32_t M,
+                          int32_t H, int32_t W, void* workspace, int64_t workspace_floats, void* stream);
 /* GMA Attention.forward (gma.py:54-76), 1 head x 128: attn [B,N,N] = softmax(128^-0.5 q k^T),
  * [q|k] = inp . w_qk^T (w_qk [256,128]); qk scratch [B*N,256].                                        */
 int st_gma_attention(const float* inp, int32_t ld_inp, const float* w_qk, float* qk, float* attn, int32_t B,
@@ -391,6 +401,12 @@ int st_sepconv_gru(float* hxA, float* hxB, int32_t ld, float* zbuf, const float*
  * st_sepconv_gru_split3 (gru.py:44-59): hxA_planes / hxB_planes image hxA = [h | x] and hxB = [r*h | -] (ld channels, ld % 32 == 0);
  * r*h exists only as planes; the new h goes to hxA (fp32, in place) and to columns 0..127 of hxA_planes; w_* are st_split3_pack
  * images of the fp32 operator's weight matrices.                                                                                   */
+/* st_gma_aggregate whose result ALSO leaves as blocked bf16 planes (columns out_col..out_col+127 of out_planes; st_gemm_desc.c_planes): the
+ * aggregate reads the whole attention matrix every call and is HBM-bound on either operand format, so it stays on the fp32 kernel while
+ * its consumer (st_sepconv_gru_split3) reads planes.  gma.py:102-115.                                                              */
+int st_gma_aggregate_planes(const float* attn, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma, float* vT,
+                            float* out, int32_t ld_out, void* out_planes, int64_t out_pstride, int64_t out_prows, int32_t out_col, int32_t B,
+                            int32_t N, void* workspace, int64_t workspace_floats, void* stream);
 int st_gma_aggregate_split3(const void* attn_planes, int64_t attn_pstride, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma,
                             float* vT, void* vT_planes, int64_t vT_pstride, float* out, int32_t ld_out, void* out_planes, int64_t out_pstride,
                             int64_t out_prows, int32_t out_col, int32_t B, int32_t N, void* workspace, int64_t workspace_floats, void* stream);

@@ -2078,6 +2078,9 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
     if (split == 0) {
         split = 1;
         if (batch == 1 && d.workspace && d.K >= 512 && tiles < 256) split = (int)((256 + tiles - 1) / tiles);
+        // exactly one workgroup per CU (N = 128 at M = 8 192) leaves every SIMD with ONE consumer wave -- two K halves give it two
+        static const int sk2 = [] { const char* e = getenv("ST_SPLIT3_SK2"); return e ? atoi(e) : 1; }();      // measured: decoder chain 5.36 -> 5.23 ms (tools/decoder_bench.py); ST_SPLIT3_SK2=0 = off
+        if (sk2 && batch == 1 && d.workspace && d.K >= 1024 && tiles == 256 && cfg == 34) split = 2;
         if (split > d.K / 256) split = d.K / 256;
         if (split > 16) split = 16;
         if (split < 1) split = 1;

@@ -237,7 +237,7 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
     // Epilogue operands: fetched AHEAD of the K loop when the wave owns one sub-tile (48 registers; issued after it they are two or three
     // dependent L2 round trips with nothing to hide them: all workgroups of a launch finish together); for larger wave tiles AFTER it
     // (3 x 64 operand registers would have to live beside 128 accumulator + 96 fragment registers at two waves per SIMD).
-    constexpr bool EPI_AHEAD = false;     // (48 more registers would push the 64x64 configuration past 128: one workgroup per CU instead of two)
+    constexpr bool EPI_AHEAD = TM * TN == 1;
     EpiOperands<TM, TN> eop;
     if (EPI_AHEAD) {
         gemm_epilogue_consts<TM, TN>(d, eop, n0, wn, li, split);

@@ -112,6 +112,28 @@ int st_patch_embed(const float* cost_maps, const float* const* weights, int32_t 
     return st_layernorm(tokens, 128, weights[9], weights[10], tokens, 128, M * P, 128, 1e-5f, stream);
 }
 
+// st_patch_embed for 64x64 cost maps with the third convolution (Conv2d(32,64,6,2,2), 77 of the operator's 99 GFLOP per pair) on exact-split
+// operands (st_gemm_desc.split3): the fused c0 + c2 launch emits its result as bf16 planes (s2_planes: [3][1][M*256][32], s2_pstride elements
+// apart, no fp32 copy), c4_w_planes = st_split3_pack of c4_w [64, 1152].  M * 256 * 32 * 6 bytes must stay below 2 GiB (M <= 16 384 maps per call).
+int st_patch_embed_split3(const float* cost_maps, const float* const* weights, int32_t ld_f0, const float* pe_bias, void* s2_planes,
+                          int64_t s2_pstride, const void* c4_w_planes, int64_t c4_w_pstride, float* s3, float* s4, float* tokens, int32_t M,
+                          int32_t H, int32_t W, void* workspace, int64_t workspace_floats, void* stream) {
+    if (!cost_maps || !weights || !pe_bias || !s2_planes || !c4_w_planes || !s3 || !s4 || !tokens || M <= 0 || H != 64 || W != 64) return ST_EINVAL;
+    const int H2 = 16, W2 = 16, H3 = 8, W3 = 8, P = 64;
+    ST_TRY(st_patch_conv12_planes(cost_maps, weights[0], weights[1], weights[2], weights[3], s2_planes, s2_pstride, M, H, W, stream));
+    {
+        Gemm g((const float*)s2_planes, 32, (const float*)c4_w_planes, 1152, s3, 64, 0, 64, 32);
+        g.conv(M, H2, W2, 6, 6, 2, 2, 2, 2, H3, W3).bias(weights[5]).work(workspace, workspace_floats);
+        g.d.split3 = 1; g.d.a_plane_stride = s2_pstride; g.d.a_rows = (int64_t)M * H2 * W2; g.d.w_plane_stride = c4_w_pstride; g.d.w_rows = 64;
+        ST_TRY(g.run(stream));
+    }
+    ST_TRY(Gemm(s3, 64, weights[6], ld_f0, s4, 128, M * P, 128, 64).aux0(pe_bias, 128, 0, P).act(ST_ACT_RELU)
+               .work(workspace, workspace_floats).run(stream));
+    ST_TRY(Gemm(s4, 128, weights[7], 128, tokens, 128, M * P, 128, 128).bias(weights[8])
+               .work(workspace, workspace_floats).run(stream));
+    return st_layernorm(tokens, 128, weights[9], weights[10], tokens, 128, M * P, 128, 1e-5f, stream);
+}
+
 // GMA Attention.forward (gma.py:54-76), heads = 1, dim_head = 128: attn[b] = softmax(scale * q k^T) with
 // [q | k] = inp . Wqk^T.  qk: scratch [B*N, 256]; attn: [B, N, N].
 int st_gma_attention(const float* inp, int32_t ld_inp, const float* w_qk, float* qk, float* attn, int32_t B, int32_t N,
@@ -126,9 +148,24 @@ int st_gma_attention(const float* inp, int32_t ld_inp, const float* w_qk, float*
 // GMA Aggregate.forward (gma.py:102-115), heads = 1: out = mf + gamma * (attn @ (mf . Wv^T)).
 // v is produced transposed (vT[b] = Wv . mf[b]^T, [128, N]) so that attn @ v is again an  A . W^T  contraction.
 // mf/out: rows [B*N, ld] (column slices of the GRU input buffer); vT: scratch [B, 128, N].
+static int gma_aggregate_impl(const float* attn, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma, float* vT,
+                              float* out, int32_t ld_out, void* out_planes, int64_t out_pstride, int64_t out_prows, int32_t out_col, int32_t B,
+                              int32_t N, void* workspace, int64_t workspace_floats, void* stream);
 int st_gma_aggregate(const float* attn, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma, float* vT,
                      float* out, int32_t ld_out, int32_t B, int32_t N, void* workspace, int64_t workspace_floats,
                      void* stream) {
+    return gma_aggregate_impl(attn, mf, ld_mf, w_v, gamma, vT, out, ld_out, nullptr, 0, 0, 0, B, N, workspace, workspace_floats, stream);
+}
+// the same, the result ALSO emitted as blocked bf16 planes (columns out_col .. out_col+127 of out_planes) for a split3 consumer
+int st_gma_aggregate_planes(const float* attn, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma, float* vT,
+                            float* out, int32_t ld_out, void* out_planes, int64_t out_pstride, int64_t out_prows, int32_t out_col, int32_t B,
+                            int32_t N, void* workspace, int64_t workspace_floats, void* stream) {
+    if (!out_planes) return ST_EINVAL;
+    return gma_aggregate_impl(attn, mf, ld_mf, w_v, gamma, vT, out, ld_out, out_planes, out_pstride, out_prows, out_col, B, N, workspace, workspace_floats, stream);
+}
+static int gma_aggregate_impl(const float* attn, const float* mf, int32_t ld_mf, const float* w_v, const float* gamma, float* vT,
+                              float* out, int32_t ld_out, void* out_planes, int64_t out_pstride, int64_t out_prows, int32_t out_col, int32_t B,
+                              int32_t N, void* workspace, int64_t workspace_floats, void* stream) {
     if (!attn || !mf || !w_v || !gamma || !vT || !out || B <= 0 || N <= 0) return ST_EINVAL;
     // both products run as batched launches over b (grid.z): vT[b] = Wv . mf[b]^T, then out[b] = mf[b] + gamma attn[b] vT[b]^T
     ST_TRY(Gemm(w_v, 128, mf, ld_mf, vT, N, 128, N, 128).batched(B, 0, (int64_t)N * ld_mf, (int64_t)128 * N).run(stream));
@@ -136,6 +173,10 @@ int st_gma_aggregate(const float* attn, const float* mf, int32_t ld_mf, const fl
         Gemm g(attn, N, vT, N, out, ld_out, N, 128, N);
         g.epi(ST_EPI_AXPY, mf, ld_mf).scale(gamma).batched(B, (int64_t)N * N, (int64_t)128 * N, (int64_t)N * ld_out);
         g.d.batch_stride_aux1 = (int64_t)N * ld_mf;
+        if (out_planes) {
+            g.d.c_planes = out_planes; g.d.c_plane_stride = out_pstride; g.d.c_plane_rows = out_prows; g.d.c_plane_col0 = out_col;
+            g.d.c_plane_batch_rows = N;
+        }
         if (B == 1) g.work(workspace, workspace_floats);        // a single map cannot fill the chip without split-K
         ST_TRY(g.run(stream));
     }

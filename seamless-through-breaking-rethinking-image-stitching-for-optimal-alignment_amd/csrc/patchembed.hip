@@ -59,7 +59,8 @@ __device__ __forceinline__ pe_i32x4 pe_make_rsrc(const void* base, unsigned byte
 
 __global__ __launch_bounds__(256, 2) void patch_c0c2_kernel(const float* __restrict__ maps, const float* __restrict__ w0,
                                                             const float* __restrict__ b0, const float* __restrict__ w2,
-                                                            const float* __restrict__ b2, float* __restrict__ out, int M) {
+                                                            const float* __restrict__ b2, float* __restrict__ out, int M,
+                                                            __bf16* __restrict__ out_planes, long long out_pstride) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     float* ring = smem;                                  // [PE_STAGES][32 n][32 k], rows of 128 B, chunk-swizzled like the GEMM's B tile
     float* img = smem + PE_STAGES * 1024;                // [44][68]
@@ -190,7 +191,25 @@ __global__ __launch_bounds__(256, 2) void patch_c0c2_kernel(const float* __restr
         }
         acc = acc + tot;
         // ---- epilogue: bias + ReLU, rows 32 wave + 4 lh + ROW(r) of the unit, column li
-        {
+        if (out_planes) {
+            // st_patch_conv12_planes: the result leaves as the three blocked bf16 planes a split3 consumer reads (32 channels = ONE chunk, so
+            // element (row, channel) sits at row * 32 + channel in every plane); lane pairs exchange halves, the even lane stores the dword
+            unsigned* o = reinterpret_cast<unsigned*>(out_planes + ((size_t)m * 256 + 128 * h + 32 * wave + 4 * lh) * 32 + li);
+            const size_t ps2 = (size_t)out_pstride / 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                __bf16 hh, mm, ll;
+                st_split3(fmaxf(fmaf(acc[r], 1.0f, bv2), 0.f), hh, mm, ll);
+                const unsigned ph = st_bf16_bits(hh), pm = st_bf16_bits(mm), pl = st_bf16_bits(ll);
+                const unsigned nh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ph, 0xB1, 0xF, 0xF, false);
+                const unsigned nm = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0xB1, 0xF, 0xF, false);
+                const unsigned nl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pl, 0xB1, 0xF, 0xF, false);
+                if (!(li & 1)) {
+                    unsigned* q = o + (size_t)((r & 3) + 8 * (r >> 2)) * 16;
+                    q[0] = ph | (nh << 16); q[ps2] = pm | (nm << 16); q[2 * ps2] = pl | (nl << 16);
+                }
+            }
+        } else {
             float* o = out + ((size_t)m * 256 + 128 * h + 32 * wave + 4 * lh) * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * 32] = fmaxf(fmaf(acc[r], 1.0f, bv2), 0.f);
@@ -199,9 +218,22 @@ __global__ __launch_bounds__(256, 2) void patch_c0c2_kernel(const float* __restr
 }
 
 // cost maps [M, 64*64] -> s2 rows [M*16*16, 32] (channels last) = ReLU(c2(ReLU(c0(map)))).
+static int patch_conv12_impl(const float* cost_maps, const float* c0_w36x16, const float* c0_b, const float* c2_w32x576, const float* c2_b,
+                             float* s2, void* s2_planes, int64_t s2_pstride, int32_t M, int32_t H, int32_t W, void* stream);
 extern "C" int st_patch_conv12(const float* cost_maps, const float* c0_w36x16, const float* c0_b, const float* c2_w32x576, const float* c2_b,
                                float* s2, int32_t M, int32_t H, int32_t W, void* stream) {
-    if (!cost_maps || !c0_w36x16 || !c0_b || !c2_w32x576 || !c2_b || !s2 || M <= 0) return ST_EINVAL;
+    if (!s2) return ST_EINVAL;
+    return patch_conv12_impl(cost_maps, c0_w36x16, c0_b, c2_w32x576, c2_b, s2, nullptr, 0, M, H, W, stream);
+}
+// the same with the result as three blocked bf16 planes [1 chunk][M * 256 rows][32] (st_gemm_desc.split3 operand format), s2_pstride elements apart
+extern "C" int st_patch_conv12_planes(const float* cost_maps, const float* c0_w36x16, const float* c0_b, const float* c2_w32x576, const float* c2_b,
+                                      void* s2_planes, int64_t s2_pstride, int32_t M, int32_t H, int32_t W, void* stream) {
+    if (!s2_planes || s2_pstride < (int64_t)M * 256 * 32 || (s2_pstride & 7) || ((uintptr_t)s2_planes & 15)) return ST_EINVAL;
+    return patch_conv12_impl(cost_maps, c0_w36x16, c0_b, c2_w32x576, c2_b, nullptr, s2_planes, s2_pstride, M, H, W, stream);
+}
+static int patch_conv12_impl(const float* cost_maps, const float* c0_w36x16, const float* c0_b, const float* c2_w32x576, const float* c2_b,
+                             float* s2, void* s2_planes, int64_t s2_pstride, int32_t M, int32_t H, int32_t W, void* stream) {
+    if (!cost_maps || !c0_w36x16 || !c0_b || !c2_w32x576 || !c2_b || (!s2 && !s2_planes) || M <= 0) return ST_EINVAL;
     if (H != 64 || W != 64) return ST_EINVAL;            // the per-map LDS images are sized for the 512x512 configuration; callers fall back
     if (((uintptr_t)cost_maps | (uintptr_t)c2_w32x576) & 15) return ST_EINVAL;
     (void)hipFuncSetAttribute((const void*)patch_c0c2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PE_LDS_BYTES);
@@ -214,7 +246,8 @@ extern "C" int st_patch_conv12(const float* cost_maps, const float* c0_w36x16, c
     od.M = M * 256; od.N = 32; od.K = 576; od.H = 64; od.W = 64; od.Cin = 1; od.ldx = 1; od.ldw = 576; od.ldc = 32;
     od.kh = od.kw = 6; od.sh = od.sw = 2; od.ph = od.pw = 2; od.Ho = od.Wo = 16; od.batch = 1; od.alpha = 1.f; od.act = ST_ACT_RELU;
     st_internal_observe(&od, stream, 0, 7);
-    hipLaunchKernelGGL(patch_c0c2_kernel, dim3(G), dim3(256), PE_LDS_BYTES, (hipStream_t)stream, cost_maps, c0_w36x16, c0_b, c2_w32x576, c2_b, s2, M);
+    hipLaunchKernelGGL(patch_c0c2_kernel, dim3(G), dim3(256), PE_LDS_BYTES, (hipStream_t)stream, cost_maps, c0_w36x16, c0_b, c2_w32x576, c2_b, s2, M,
+                       (__bf16*)s2_planes, (long long)s2_pstride);
     st_internal_observe(&od, stream, 1, 7);
     ST_CHECK_LAUNCH();
     return ST_OK;

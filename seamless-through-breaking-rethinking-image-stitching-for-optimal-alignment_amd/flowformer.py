@@ -48,7 +48,9 @@ SPLIT3 = os.environ.get("ST_SPLIT3", "1") != "0"
 FUSE_PE = os.environ.get("ST_FUSE_PE", "1") != "0"              # PatchEmbed c0 + c2 per cost map in one launch (csrc/patchembed.hip; the library reads the same switch)
 assert not (SPLIT3 and FORK_ENC), "ST_FORK_ENC is an fp32-path experiment"
 S3_PAIR = os.environ.get("ST_S3_PAIR", "1") != "0"
-S3_OFF = int(os.environ.get("ST_S3_OFF", "0"))     # bisecting aid: bit 1 mask-head conv, 2 flow-head conv, 4 aggregate, 8 GRU, 16 motion conv, 32 conv pair back on the fp32 kernels
+S3_PE = os.environ.get("ST_S3_PE", "1") != "0"                 # PatchEmbed's third convolution on planes
+S3_AGG = os.environ.get("ST_S3_AGG", "0") == "1"               # GMA aggregate on planes (measured equal to the fp32 kernel in the chain: HBM-bound; default off)
+S3_OFF = int(os.environ.get("ST_S3_OFF", "0"))     # bisecting aid: bit 1 mask-head conv, 2 flow-head conv, 8 GRU, 16 motion conv, 32 conv pair back on the fp32 kernels
 _SIDE = {}
 
 
@@ -131,6 +133,8 @@ class FlowFormer(ParamTree):
         pe["c0_direct"] = (p[c + "patch_embed.proj.0.weight"].reshape(16, 36).t().contiguous(), pe["c0"][1])
         pe["embed11"] = [pe["c0_direct"][0], pe["c0_direct"][1], pe["c2"][0], pe["c2"][1], pe["c4"][0], pe["c4"][1],
                          pe["f0"][0], pe["f2"][0], pe["f2"][1], pe["norm"][0], pe["norm"][1]]
+        if SPLIT3:
+            pe["c4_s3"] = ops.split3_pack(pe["c4"][0])          # [64, 36 taps * 32]: the split3 form of PatchEmbed's third convolution
         pk["pe"] = pe
         pk["latents"] = p[c + "latent_tokens"][0].contiguous()
 
@@ -336,9 +340,19 @@ class FlowFormer(ParamTree):
             ops.conv_gemm(tab_in, pe["f0"][0][:, 64:], tab, bias=pe["f0"][1])
             self._const[key] = tab
         # 64x64 maps: the first two convs run as one launch that keeps the first feature map (64 KiB per map, 537 MB per pair) on the CU
+        s3, s4, f = _new(M * P, 64, dev), _new(M * P, 128, dev), _new(M * P, 128, dev)
+        if SPLIT3 and S3_PE and FUSE_PE and H2 == 64 and W2 == 64:
+            # Conv2d(32, 64, 6, 2, 2) -- 77 of the operator's 99 GFLOP -- on exact-split operands: the fused c0 + c2 launch emits bf16 planes
+            # (no fp32 second feature map at all), in chunks of <= 16 384 maps (2 GiB buffer offsets)
+            CH = 16384
+            s2p = ops.Planes(min(M, CH) * 256, 32, dev)
+            for m0 in range(0, M, CH):
+                m1 = min(M, m0 + CH)
+                ops.patch_embed_split3(cost_maps[m0:m1], pe["embed11"], pe["f0"][0].stride(0), self._const[key], s2p, pe["c4_s3"],
+                                       s3[m0 * P:m1 * P], s4[m0 * P:m1 * P], f[m0 * P:m1 * P], m1 - m0, H2, W2)
+            return f, P
         s1 = None if (H2 == 64 and W2 == 64 and FUSE_PE) else _new(M * H1 * W1, 16, dev)
         s2 = _new(M * H2p * W2p, 32, dev)
-        s3, s4, f = _new(M * P, 64, dev), _new(M * P, 128, dev), _new(M * P, 128, dev)
         ops.patch_embed(cost_maps, pe["embed11"], pe["f0"][0].stride(0), self._const[key], s1, s2, s3, s4, f, M, H2, W2)
         return f, P
 
@@ -544,7 +558,7 @@ class FlowFormer(ParamTree):
         if S["s3"]:
             W3 = D["s3"]
             hxA_p = S["hxA_p"]
-            if torch.is_tensor(attn):      # a caller that built the attention matrix itself (tests): its planes, here
+            if S3_AGG and torch.is_tensor(attn):      # a caller that built the attention matrix itself (tests): its planes, here
                 attn = ops.split3_pack(attn.view(B * N, N))
             # convc1 (K = 160) stays on the fp32 kernel and emits cor1's planes; flow_encode emits flo1's and the flow's two channels
             ops.conv_gemm(corr, D["convc1"][0], S["cor1"], bias=D["convc1"][1], act="relu", out_planes=S["cor1_p"])
@@ -565,11 +579,12 @@ class FlowFormer(ParamTree):
                 ops.conv_gemm(S["corflo"], D["conv"][0], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu", out_planes=hxA_p.cols(128, 256))
             else:
                 ops.conv_gemm(S["corflo_p"], W3["conv"], hxA[:, 128:254], geom=g3, bias=D["conv"][1], act="relu", out_planes=hxA_p.cols(128, 256))
-            if S3_OFF & 4:
-                ops.gma_aggregate(S["attn_f32"], hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], hxA[:, 256:], B, N)
-                ops.split3_pack(hxA[:, 256:], out=hxA_p.cols(256, 384))
-            else:
+            if S3_AGG:
                 ops.gma_aggregate_split3(attn, hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], S["vT_p"], hxA[:, 256:], hxA_p.cols(256, 384), B, N)
+            else:
+                # the aggregate reads the whole attention matrix every iteration and is HBM-bound either way (fp32: 134 MB per launch, 64.8 us in
+                # the chain; planes: 201 MB, 66.2 us): it stays on the fp32 kernel, whose epilogue emits the planes of its result
+                ops.gma_aggregate(attn, hxA[:, 128:256], D["to_v"], D["gamma"], S["vT"], hxA[:, 256:], B, N, out_planes=hxA_p.cols(256, 384))
             if S3_OFF & 8:
                 ops.sepconv_gru(hxA, hxB, S["zbuf"], gru_tab["1"], gru_tab["2"], D["zr1"], D["q1"], D["zr2"], D["q2"], B, H1, W1)
                 ops.split3_pack(hxA[:, :128], out=hxA_p.cols(0, 128))
@@ -629,9 +644,7 @@ class FlowFormer(ParamTree):
         qk = _new(R, 256, dev)
         attn = torch.empty((B, N, N), device=dev)
         ops.gma_attention(inp, D["qk"], qk, attn, B, N)
-        if S["s3"]:                # the attention matrix is read 12 times as a contraction operand: its planes, once per pass
-            if S3_OFF & 4:
-                S["attn_f32"] = attn
+        if S["s3"] and S3_AGG:     # (ST_S3_AGG=1: the aggregate on planes too: the attention matrix's planes, once per pass)
             attn = ops.split3_pack(attn.view(B * N, N))
         return dict(S=S, inp=inp, gru_tab=gru_tab, attn=attn, qk=qk)
 

@@ -461,13 +461,27 @@ def patch_embed(cost_maps, weights11, ld_f0, pe_bias, s1, s2, s3, s4, tokens, M,
     return tokens
 
 
+def patch_embed_split3(cost_maps, weights11, ld_f0, pe_bias, s2_planes, c4_w_planes, s3, s4, tokens, M, H, W):
+    """patch_embed for 64 x 64 maps with the third convolution on exact-split operands (st_patch_embed_split3); s2_planes = Planes(M*256, 32)."""
+    arr = (C.c_void_p * 11)(*[w.data_ptr() for w in weights11])
+    check(lib.st_patch_embed_split3(_pc(cost_maps), arr, ld_f0, _pc(pe_bias), C.c_void_p(s2_planes.ptr()), s2_planes.pstride, C.c_void_p(c4_w_planes.ptr()),
+                                    c4_w_planes.pstride, _pc(s3), _pc(s4), _pc(tokens), M, H, W, *_ws(cost_maps.device), _stream()), "st_patch_embed_split3")
+    return tokens
+
+
 def gma_attention(inp, w_qk, qk, attn, B, N):
     check(lib.st_gma_attention(_p(inp), _ld(inp), _pc(w_qk), _pc(qk), _pc(attn), B, N, *_ws(inp.device), _stream()),
           "st_gma_attention")
     return attn
 
 
-def gma_aggregate(attn, mf, w_v, gamma, vT, out, B, N):
+def gma_aggregate(attn, mf, w_v, gamma, vT, out, B, N, out_planes=None):
+    """out = mf + gamma * attn @ (mf . w_v^T) (st_gma_aggregate); out_planes (a Planes column slice): the result also leaves as planes
+    (st_gma_aggregate_planes: the same two fp32-MFMA launches, the second one's epilogue emits them)."""
+    if out_planes is not None:
+        check(lib.st_gma_aggregate_planes(_pc(attn), _p(mf), _ld(mf), _pc(w_v), _p(gamma), _pc(vT), _p(out), _ld(out), C.c_void_p(out_planes.t.data_ptr()),
+                                          out_planes.pstride, out_planes.rows, out_planes.c0, B, N, *_ws(mf.device), _stream()), "st_gma_aggregate_planes")
+        return out
     check(lib.st_gma_aggregate(_pc(attn), _p(mf), _ld(mf), _pc(w_v), _p(gamma), _pc(vT), _p(out), _ld(out), B, N,
                                *_ws(mf.device), _stream()), "st_gma_aggregate")
     return out

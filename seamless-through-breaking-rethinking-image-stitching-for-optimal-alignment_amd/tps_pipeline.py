@@ -104,19 +104,54 @@ def sample_init_points(residual_flow, out_height, out_width, width_min, height_m
     step = max(H, W) // min(grid_h, grid_w)
     crop = H_warp[:, :, top:top + H, left:left + W].contiguous()
     grad = ops.sobel_magnitude(crop)
-    src = tgt = None
-    for method in get_pt_methods:
-        bp = advanced_uniform_sample_border_points(crop, step, pad_num, _grad=grad)
+    # ONE device -> host round trip for the whole sampling stage (was one per border-sampling call + one for the flow lookup, 4-5 per pair:
+    # VERDICT r5 item 8): every range_argmax of every method is enqueued first, the flow vectors of ALL candidate sites are gathered on the
+    # stream behind them, and both come back together; the per-call de-duplication (np.unique, as sample_point_methods.py does it) and the
+    # flow-limit selection then run on the host on those few hundred rows -- same points, same order as the call-by-call form.
+    dev = crop.device
+    calls = []                                   # (method index, device tensor of flat argmax positions)
+    for mi, method in enumerate(get_pt_methods):
+        if method not in ("advanced_uniform", "advanced_uniform_multi"):
+            raise NotImplementedError(method)
+        pads = [pad_num]
         if method == "advanced_uniform_multi":
             p = step
             while p <= max(H, W) // 4:
-                bp = torch.cat((bp, advanced_uniform_sample_border_points(crop, step, p, _grad=grad)), dim=0)
+                pads.append(p)
                 p *= 2
-        elif method != "advanced_uniform":
-            raise NotImplementedError(method)
-        s, t = get_point_pairs(bp, residual_flow, flow_limit)
-        src = s if src is None else torch.cat((src, s), 1)
-        tgt = t if tgt is None else torch.cat((tgt, t), 1)
+        for pad in pads:
+            if pad < 2:
+                raise NotImplementedError("pad_num < 2 makes the reference's slice starts negative (wrap-around); not supported")
+            ranges = border_ranges(H, W, step, pad)
+            if ranges:
+                calls.append((mi, ops.range_argmax(grad, torch.tensor(ranges, dtype=torch.int32, device=dev))))
+    src = tgt = None
+    if calls:
+        flat_dev = torch.cat([c[1].reshape(-1) for c in calls]).to(torch.int64)
+        pts_dev = torch.stack([flat_dev % W, flat_dev // W], 1).to(torch.int32).contiguous()
+        fl_dev = ops.gather_points(residual_flow[0], pts_dev)                                    # [n_candidates, 2]
+        both = torch.cat([flat_dev.to(torch.float64).unsqueeze(1), fl_dev.to(torch.float64)], 1).cpu().numpy()      # the round trip
+        flat_all, fl_all = both[:, 0].astype(np.int64), both[:, 1:].astype(np.float32)
+        off = 0
+        per_method = {}
+        for mi, t in calls:
+            n = t.numel()
+            flat = flat_all[off:off + n]
+            pts = np.stack([flat % W, flat // W], 1)
+            uniq, first = np.unique(pts, axis=0, return_index=True)
+            per_method.setdefault(mi, []).append((torch.from_numpy(uniq), torch.from_numpy(fl_all[off:off + n][first])))
+            off += n
+        lim = (H + W) // 2 // 8 if flow_limit == -1 else flow_limit
+        for mi in sorted(per_method):
+            bp = torch.cat([u for u, _ in per_method[mi]], 0).unsqueeze(0)
+            fl = torch.cat([f for _, f in per_method[mi]], 0).unsqueeze(0)
+            if lim is not None:
+                a = fl.abs()
+                sel = (a[:, :, 0] < lim) & (a[:, :, 1] < lim)
+                bp, fl = bp[sel].view(1, -1, 2), fl[sel].view(1, -1, 2)
+            s, t = bp, bp + fl
+            src = s if src is None else torch.cat((src, s), 1)
+            tgt = t if tgt is None else torch.cat((tgt, t), 1)
     if src is None:
         raise Exception("src_points is None and non_shifted_src_points is None")
     sh = lambda x: shift_points(x, width_min, None, height_min, None, H, W, pad_num)          # noqa: E731
