@@ -122,7 +122,8 @@ int st_set_gemm_observer(void* callback, void* user);
 /* Profiling aid: the launch plan the library chose for the calling thread's most recent st_conv_gemm:
  *   plan4[0] kernel family (0 skinny_gemm, 1 narrow_conv, 2 conv_gemm_kernel [register-staged], 3 conv_gemm_dma_kernel,
  *            4 rowstream_gemm_kernel, 5 rowchain128_kernel [st_linear_chain128, reported to the observer as M x 128L x 128],
- *            6 rowmlp128_kernel [st_mlp128, reported as M x 2 hidden x 128])
+ *            6 rowmlp128_kernel [st_mlp128, reported as M x 2 hidden x 128], 7 patch_c0c2_kernel [st_patch_conv12], 8 conv_gemm_split3_kernel
+ *            [st_gemm_desc.split3: tile_cfg 31..36])
  *   plan4[1] tile_cfg actually used, plan4[2] split_k actually used, plan4[3] 1 = persistent M walk, 2 / 3 = first / second
  *            member of an st_conv_gemm_pair launch (one dispatch, reported with the second member).
  * Used by tools/gemm_shapes_csv.py to label every launch of a step (profiles/r2_gemm_shapes.csv). */

@@ -2092,7 +2092,7 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
         split = (nkt + per - 1) / per;                     // no empty slice
     }
     d.split_k = split;
-    g_last_plan[0] = 7; g_last_plan[1] = cfg; g_last_plan[2] = split; g_last_plan[3] = 0;
+    g_last_plan[0] = 8; g_last_plan[1] = cfg; g_last_plan[2] = split; g_last_plan[3] = 0;
     hipStream_t s = (hipStream_t)stream;
     // timing experiments (tools/split3_probe.py --diag): ST_SPLIT3_DIAG=1 consumers skip the MFMAs, 2 loaders skip the DMA; results are garbage
     static const int diag = [] { const char* e = getenv("ST_SPLIT3_DIAG"); return e ? atoi(e) : 0; }();
@@ -2167,7 +2167,7 @@ extern "C" int st_conv_gemm_pair(const st_gemm_desc* desc0, const st_gemm_desc* 
         g.tiles0 = tiles3(g.d[0]);
         const int total3 = g.tiles0 + tiles3(g.d[1]);
         st_gemm_observer_fn obs3 = g_observer;
-        g_last_plan[0] = 7; g_last_plan[1] = 34; g_last_plan[2] = 1; g_last_plan[3] = 2;
+        g_last_plan[0] = 8; g_last_plan[1] = 34; g_last_plan[2] = 1; g_last_plan[3] = 2;
         if (obs3) { obs3(desc0, stream, 0, g_observer_user); obs3(desc0, stream, 1, g_observer_user); obs3(desc1, stream, 0, g_observer_user); }
         g_last_plan[3] = 3;
         auto k3 = conv_gemm_split3_pair_kernel<2, 2, 1, 1, 3>;

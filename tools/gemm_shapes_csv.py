@@ -22,7 +22,7 @@ import sys
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 
 FAMILY = {0: "skinny_gemm_kernel", 1: "narrow_conv_kernel", 2: "conv_gemm_kernel", 3: "conv_gemm_dma_kernel", 4: "rowstream_gemm_kernel", 5: "rowchain128_kernel",
-          6: "rowmlp128_kernel", 7: "patch_c0c2_kernel"}
+          6: "rowmlp128_kernel", 7: "patch_c0c2_kernel", 8: "conv_gemm_split3_kernel"}
 PEAK = 157.3
 
 
@@ -64,10 +64,16 @@ def timing_pass(out_csv, launches_json=None, profile_only=False):
             # fused row kernels (reported as M x 128 L x 128 / M x 2 hidden x 128): the intermediate activations never move --
             # A rows in, weights, 128-wide rows out (+ the residual rows re-read by the MLP kernel)
             alg = 4.0 * (d.M * 128 + d.M * 128) + w_bytes + (4.0 * d.M * 128 if plan[0] == 6 else 0.0)
+        elif d.split3:
+            # exact-split operands: three bf16 planes = 6 bytes per element of A and W
+            w_bytes = 6.0 * nb * d.N * d.K
+            alg = nb * (6.0 * a_rows * d.Cin + (0.0 if d.c_no_f32 else 4.0 * d.M * d.N)) + w_bytes
         else:
             alg = 4.0 * nb * (a_rows * d.Cin + d.M * d.N) + w_bytes
             if d.c_t:
                 alg += 4.0 * nb * d.M * d.N                       # the transposed second store of st_corr_volume_both
+        if d.c_planes:                                            # the result also leaves as planes (6 bytes per element)
+            alg += 6.0 * nb * d.M * (d.N // 2 if d.epi == 5 else d.N)
         rec.append(dict(M=d.M, N=d.N, K=d.K, conv=f"{d.kh}x{d.kw}s{d.sh}" + (f"d{d.dh}" if d.dh > 1 else ""), batch=nb,
                         kernel=FAMILY.get(plan[0], "?"), tile=plan[1], split_k=plan[2], persist=plan[3], epi=d.epi,
                         flops=2.0 * d.M * d.N * d.K * nb, alg_bytes=alg, w_bytes=w_bytes,
@@ -110,7 +116,7 @@ def merge_pairs(rec):
         if r["persist"] == 2 and i + 1 < len(rec) and rec[i + 1]["persist"] == 3:
             m = dict(r)
             o = rec[i + 1]
-            m.update(N=f"{r['N']}+{o['N']}", kernel="conv_gemm_dma_pair_kernel", persist=0, us=r["us"] + o["us"], flops=r["flops"] + o["flops"],
+            m.update(N=f"{r['N']}+{o['N']}", kernel="conv_gemm_split3_pair_kernel" if "split3" in r["kernel"] else "conv_gemm_dma_pair_kernel", persist=0, us=r["us"] + o["us"], flops=r["flops"] + o["flops"],
                      alg_bytes=r["alg_bytes"] + o["alg_bytes"], w_bytes=r.get("w_bytes", 0.0) + o.get("w_bytes", 0.0))
             if "fetch_bytes" in o:
                 m["fetch_bytes"] = r.get("fetch_bytes", 0.0) + o["fetch_bytes"]
