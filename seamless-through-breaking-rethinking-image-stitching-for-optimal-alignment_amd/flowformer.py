@@ -133,7 +133,7 @@ class FlowFormer(ParamTree):
         pe["c0_direct"] = (p[c + "patch_embed.proj.0.weight"].reshape(16, 36).t().contiguous(), pe["c0"][1])
         pe["embed11"] = [pe["c0_direct"][0], pe["c0_direct"][1], pe["c2"][0], pe["c2"][1], pe["c4"][0], pe["c4"][1],
                          pe["f0"][0], pe["f2"][0], pe["f2"][1], pe["norm"][0], pe["norm"][1]]
-        if SPLIT3:
+        if SPLIT3 and pe["c4"][0].is_cuda:               # (a pack on the CPU -- layout tests -- has no planes: the module cannot run there anyway)
             pe["c4_s3"] = ops.split3_pack(pe["c4"][0])          # [64, 36 taps * 32]: the split3 form of PatchEmbed's third convolution
         pk["pe"] = pe
         pk["latents"] = p[c + "latent_tokens"][0].contiguous()
@@ -235,7 +235,7 @@ class FlowFormer(ParamTree):
             dec["q" + sfx] = parts["q"][0]
             dec["inp" + sfx] = (torch.cat([parts[g][1] for g in ("z", "r", "q")], 0).contiguous(),
                                 torch.cat([parts[g][2] for g in ("z", "r", "q")], 0).contiguous())
-        if SPLIT3:
+        if SPLIT3 and dec["zr1"].is_cuda:
             # exact three-way bf16 split of the weights of the split3 launches, once (K ordered (tap, channel) as in the fp32 matrices)
             dec["s3"] = {k: ops.split3_pack(dec[k] if torch.is_tensor(dec[k]) else dec[k][0])
                          for k in ("zr1", "q1", "zr2", "q2", "convc2", "convf2", "conv", "fh1", "m0")}
@@ -341,7 +341,7 @@ class FlowFormer(ParamTree):
             self._const[key] = tab
         # 64x64 maps: the first two convs run as one launch that keeps the first feature map (64 KiB per map, 537 MB per pair) on the CU
         s3, s4, f = _new(M * P, 64, dev), _new(M * P, 128, dev), _new(M * P, 128, dev)
-        if SPLIT3 and S3_PE and FUSE_PE and H2 == 64 and W2 == 64:
+        if SPLIT3 and S3_PE and FUSE_PE and H2 == 64 and W2 == 64 and "c4_s3" in pe:
             # Conv2d(32, 64, 6, 2, 2) -- 77 of the operator's 99 GFLOP -- on exact-split operands: the fused c0 + c2 launch emits bf16 planes
             # (no fp32 second feature map at all), in chunks of <= 16 384 maps (2 GiB buffer offsets)
             CH = 16384
@@ -538,7 +538,7 @@ class FlowFormer(ParamTree):
         S = dict(hxA=_new(R, 384, dev), hxB=_new(R, 384, dev), corr=_new(R, 160, dev, zero=True),
                  cor1=_new(R, 256, dev), corflo=_new(R, 256, dev), flo1=_new(R, 128, dev),
                  vT=torch.empty((B, 128, N), device=dev), zbuf=_new(R, 128, dev), fh=_new(R, 256, dev))
-        S["s3"] = SPLIT3 and N % 32 == 0          # (plane rows are whole 32-row tiles; other map sizes keep the fp32 kernels)
+        S["s3"] = SPLIT3 and N % 32 == 0 and "s3" in self._pk["dec"]          # (plane rows are whole 32-row tiles; other map sizes keep the fp32 kernels)
         if S["s3"]:
             # plane images (ops.Planes) of the tensors the split3 contractions read; hxB's image only ever holds r*h (columns 0..127) but
             # shares hxA's strides (second A source of the q convs).  Every channel that is read is written first in each iteration:
