@@ -79,7 +79,8 @@ typedef struct st_gemm_desc {
                               K order (ky, kx, c / 32)).  ldx / ldw are ignored; batch strides are bf16 elements inside each plane.  The six
                               products hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi are accumulated in fp32 (dropped terms <= 2^-23 |a||b|);
                               epilogue, split-K and outputs exactly as the fp32 kernels.  Cin % 32 == 0; tile_cfg 0 = auto, 31: 128x128,
-                              32: 128x64, 33: 64x128, 34: 64x64; c_t and a_ln are rejected.                                                 */
+                              32: 128x64, 33: 64x128, 34: 64x64, 37: 64x64 PERSISTENT walk over the tiles (many short tiles; the only one that
+                              takes c_t); a_ln is rejected.                                                 */
     int32_t reserved3;     /* must be 0 */
     int64_t a_plane_stride, w_plane_stride, a_rows, w_rows;
     void* c_planes;        /* optional (any kernel of the family, fp32 or split3 operands): the result ALSO leaves as three blocked bf16 planes
@@ -104,6 +105,11 @@ int st_conv_gemm(const st_gemm_desc* desc, void* stream);
  * planes[p * plane_stride + ((c / 32) * chunk_rows + row) * 32 + c % 32], p = 0 (hi), 1 (mid), 2 (lo); x == hi + mid + lo exactly
  * (+-inf / NaN stay in hi alone).  Used once per weight at pack time and for activations no split3-emitting kernel produced.
  * Operands of: gru.py:44-59,246-254, gma.py:102-115, encoder.py:359-369.                                                   */
+/* All-pairs volume(s) from the feature maps' PLANES (st_split3_pack of f1 / f2 rows [B*N, C]; sample b = rows b*N ..): vol12[b] = f1[b] . f2[b]^T and, when vol21
+ * is not NULL, its transpose from the same launch -- the split3 form of st_corr_volume / st_corr_volume_both on the persistent 64x64 kernel
+ * (tile_cfg 37: a workgroup walks its tiles with one continuous DMA ring).  encoder.py:359-369.                                       */
+int st_corr_volume_split3(const void* f1_planes, const void* f2_planes, int64_t pstride, int64_t prows, float* vol12, float* vol21, int32_t B,
+                          int32_t N, int32_t C, void* stream);
 int st_split3_pack(const float* x, void* planes, int64_t rows, int32_t C, int64_t ldx, int64_t plane_stride, int64_t chunk_rows, void* stream);
 
 /* Two independent contractions in ONE launch: workgroups of both descriptors share the grid, so two mid-size convs that are

@@ -2032,7 +2032,10 @@ static int split3_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
     if (d.epi != ST_EPI_STORE && !d.aux1) return ST_EINVAL;
     if (d.epi == ST_EPI_GRU && !d.aux2) return ST_EINVAL;
     if (d.epi == ST_EPI_ZR && (!d.c2 || (d.N & 1))) return ST_EINVAL;
-    if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0 || d.reserved3 != 0 || d.c_t || d.a_ln) return ST_EINVAL;
+    if (d.reserved0 != 0 || d.reserved1 != 0 || d.reserved2 != 0 || d.reserved3 != 0 || d.a_ln) return ST_EINVAL;
+    if (d.c_t && (d.epi != ST_EPI_STORE || (d.M & 3) || (d.ld_ct & 3) || d.ld_ct < d.M || ((uintptr_t)d.c_t & 15) || d.split_k > 1 || d.a2 || d.c_planes ||
+                  (int64_t)d.N * d.ld_ct * 4 >= ((int64_t)1 << 31)))
+        return ST_EINVAL;                              // (transposed second store: the persistent 64x64 kernel only)
     if (!c_planes_ok(d)) return ST_EINVAL;
     if (d.split3 != 1) return ST_EINVAL;
     if (d.a_plane_stride <= 0 || d.w_plane_stride <= 0 || d.a_rows <= 0 || d.w_rows < d.N) return ST_EINVAL;
@@ -2069,12 +2072,19 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
     // measured (tools/split3_probe.py, profiles/r6_split3_probe.json): 128x64 tiles on a 4-stage ring win when they still give every CU a
     // workgroup (N = 256 at M = 8 192: 41.8 vs 44.2 us), 64x64 tiles (two workgroups per CU) otherwise; 128x128 never
     if (cfg == 0) cfg = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * batch >= 256 ? 32 : 34;
+    // many short tiles (>= 4 per workgroup slot, K <= 2 048): the persistent 64x64 walk (tile_cfg 37) -- the all-pairs volume, PatchEmbed's third conv
+    const long ntl64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+    static const int persist_env = [] { const char* e = getenv("ST_SPLIT3_PERSIST"); return e ? atoi(e) : 1; }();      // ST_SPLIT3_PERSIST=0: A/B switch
+    if (persist_env && d.tile_cfg == 0 && !d.a2 && d.split_k <= 1 && d.K <= 2048 && ntl64 * batch >= 2048) cfg = 37;
+    if (d.c_t) cfg = 37;
     static const int tile_env = [] { const char* e = getenv("ST_SPLIT3_TILE"); return e ? atoi(e) : 0; }();      // experiments: force one tile configuration
-    if (tile_env && d.tile_cfg == 0) cfg = tile_env;
-    static const int bms[7] = {0, 128, 128, 64, 64, 128, 64}, bns[7] = {0, 128, 64, 128, 64, 64, 64};
-    if (cfg < 31 || cfg > 36) return ST_EINVAL;
+    if (tile_env && d.tile_cfg == 0 && !d.c_t) cfg = tile_env;
+    static const int bms[8] = {0, 128, 128, 64, 64, 128, 64, 64}, bns[8] = {0, 128, 64, 128, 64, 64, 64, 64};
+    if (cfg < 31 || cfg > 37) return ST_EINVAL;
+    if (cfg == 37 && (d.a2 || d.split_k > 1)) return ST_EINVAL;
     const long tiles = (long)((d.M + bms[cfg - 30] - 1) / bms[cfg - 30]) * ((d.N + bns[cfg - 30] - 1) / bns[cfg - 30]) * batch;
     int split = d.split_k;
+    if (cfg == 37) split = 1;
     if (split == 0) {
         split = 1;
         if (batch == 1 && d.workspace && d.K >= 512 && tiles < 256) split = (int)((256 + tiles - 1) / tiles);
@@ -2100,6 +2110,18 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
     if (diag == 3) return launch_split3<2, 2, 1, 1, 3, 3>(d, s);
     if (diag == 4) return launch_split3<2, 2, 1, 1, 3, 4>(d, s);      // in-kernel clock stamps -> workspace (tools/split3_clock.py)
     if (diag == 2) return cfg == 34 ? launch_split3<2, 2, 1, 1, 3, 2>(d, s) : cfg == 32 ? launch_split3<2, 2, 2, 1, 4, 2>(d, s) : launch_split3<2, 2, 2, 2, 3, 2>(d, s);
+    if (cfg == 37) {
+        int G = 512 / batch;
+        if (G < 1) G = 1;
+        if (G > ntl64) G = (int)ntl64;
+        const size_t lds = (size_t)3 * 3 * 128 * 64;
+        void (*k)(const st_gemm_desc) = d.c_t ? conv_gemm_split3_persist_kernel<true> : conv_gemm_split3_persist_kernel<false>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        g_last_plan[3] = 1;
+        hipLaunchKernelGGL(k, dim3(G, 1, batch), dim3(512), lds, s, d);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     switch (cfg) {
         case 31: return launch_split3<2, 2, 2, 2, 3>(d, s);
         case 32: return launch_split3<2, 2, 2, 1, 4>(d, s);
@@ -2243,6 +2265,23 @@ extern "C" int st_corr_volume_both(const float* f1, const float* f2, float* vol1
     d.ldw = C; d.ldc = N; d.alpha = 1.0f;
     d.batch = B; d.batch_stride_a = (int64_t)N * C; d.batch_stride_w = (int64_t)N * C;
     d.batch_stride_c = (int64_t)N * N;
+    return st_conv_gemm(&d, stream);
+}
+
+// All-pairs volume(s) from the feature maps' planes (st_gemm_desc.split3; planes [3][C/32][rows][32], sample b = rows b*N ..): vol12[b] = f1[b] . f2[b]^T and,
+// when vol21 is given, vol21[b] = its transpose from the same launch (encoder.py:359-369 for both flow directions).
+extern "C" int st_corr_volume_split3(const void* f1_planes, const void* f2_planes, int64_t pstride, int64_t prows, float* vol12, float* vol21, int32_t B,
+                                     int32_t N, int32_t C, void* stream) {
+    if (!f1_planes || !f2_planes || !vol12 || B <= 0 || N <= 0 || C <= 0 || (C & 31) || prows < (int64_t)B * N) return ST_EINVAL;
+    st_gemm_desc d = {};
+    d.a = (const float*)f1_planes; d.w = (const float*)f2_planes; d.c = vol12; d.c_t = vol21; d.ld_ct = N;
+    d.M = N; d.N = N; d.K = C;
+    d.H = 1; d.W = N; d.Cin = C; d.ldx = C;
+    d.kh = d.kw = 1; d.sh = d.sw = 1; d.ph = d.pw = 0; d.Ho = 1; d.Wo = N;
+    d.ldw = C; d.ldc = N; d.alpha = 1.0f;
+    d.batch = B; d.batch_stride_a = (int64_t)N * 32; d.batch_stride_w = (int64_t)N * 32; d.batch_stride_c = (int64_t)N * N;
+    d.split3 = 1; d.a_plane_stride = pstride; d.w_plane_stride = pstride; d.a_rows = prows; d.w_rows = prows;
+    d.tile_cfg = 37;
     return st_conv_gemm(&d, stream);
 }
 

@@ -306,6 +306,192 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
     }
 }
 
+// PERSISTENT walk (64x64 tiles, 3-stage ring): a workgroup walks output tiles w, w + G, w + 2G, ... of its batch with ONE continuous DMA ring,
+// so the operand K steps of the next tile stream in under the epilogue of the current one.  For shapes with many tiles and a short K (the
+// all-pairs volume: K = 256 = 8 K steps per tile, 4 096 tiles per sample; PatchEmbed's third convolution: 36 K steps, 8 192 tiles) the
+// single-tile launch is all ring fill and epilogue: measured on the volume, DMA-only 600 us against MFMA-only 291 us (tools/split3_probe.py).
+// Same roles, same barrier protocol as conv_gemm_split3_body -- a tile boundary is just another K step with new addresses for the loaders, and
+// "fold, epilogue, clear" between two K steps for the consumers.  CT: the transposed second store of st_corr_volume_both.
+template <bool CT>
+__device__ __forceinline__ void conv_gemm_split3_persist_body(const st_gemm_desc& d) {
+    constexpr int BM = 64, BN = 64, ROWS = 128, STAGES = 3, WN = 2;
+    constexpr int PLANE_B = ROWS * 64, STAGE_B = 3 * PLANE_B, GA = 4, GB = 4, PA = 3, PB = 3, PPW = 6;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    char* const sm = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bz = blockIdx.z;
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN, ntl = ntm * ntn;
+    const int G = (int)gridDim.x, w = (int)blockIdx.x;
+    const int nmine = (ntl - w + G - 1) / G;                 // G <= ntl (host): every workgroup owns at least one tile
+    const int nkt = d.K / 32;
+    const int total = nmine * nkt;                           // flat (tile, K step) sequence of this workgroup
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wave - 4;
+        const char* A = reinterpret_cast<const char*>(d.a) + (size_t)bz * d.batch_stride_a * 2;
+        const char* Wt = reinterpret_cast<const char*>(d.w) + (size_t)bz * d.batch_stride_w * 2;
+        const i32x4 rsrcA = make_rsrc(A, d.a_bytes), rsrcW = make_rsrc(Wt, d.w_bytes);
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm;
+        const unsigned a_plane_b = (unsigned)(d.a_plane_stride * 2), w_plane_b = (unsigned)(d.w_plane_stride * 2);
+        const unsigned a_chunk_b = (unsigned)(d.a_rows * 64), w_chunk_b = (unsigned)(d.w_rows * 64);
+        int a_row[PA], a_iy0[PA], a_ix0[PA];
+        unsigned a_c[PA], voffA[PA], voffB[PB], ldsA[PA], ldsB[PB];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int q = lw * PA + i, plane = q / GA, rg = q % GA;
+            ldsA[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(plane * PLANE_B + rg * 1024));
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int q = lw * PB + i, plane = q / GB, rg = q % GB;
+            ldsB[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(plane * PLANE_B + BM * 64 + rg * 1024));
+        }
+        int i_c0 = 0, i_ky = 0, i_kx = 0, i_kt = 0, i_tile = w;
+        unsigned soffA = 0, soffB = 0;
+        auto set_tap = [&]() {
+            const int ty = i_ky * (d.dh > 1 ? d.dh : 1), tx = i_kx * (d.dw > 1 ? d.dw : 1);
+            const int tapoff = ty * d.W + tx;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const bool ok = (unsigned)(a_iy0[i] + ty) < (unsigned)d.H && (unsigned)(a_ix0[i] + tx) < (unsigned)d.W;
+                voffA[i] = ok ? a_c[i] + (unsigned)(a_row[i] + tapoff) * 64u : ST_OOB;
+            }
+        };
+        auto set_tile = [&](int idx) {                      // per-lane addresses of the tile's A rows (tap 0) and B rows
+            const int m0 = (idx / ntn) * BM, n0 = (idx % ntn) * BN;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int q = lw * PA + i, plane = q / GA, rg = q % GA;
+                const int r = 16 * rg + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+                const int m = min(m0 + r, d.M - 1);
+                const int hw = d.Ho * d.Wo;
+                const int b = m / hw, rr = m - b * hw;
+                const int oy = rr / d.Wo, ox = rr - oy * d.Wo;
+                a_iy0[i] = oy * d.sh - d.ph; a_ix0[i] = ox * d.sw - d.pw;
+                a_row[i] = (b * d.H + a_iy0[i]) * d.W + a_ix0[i];
+                a_c[i] = (unsigned)plane * a_plane_b + (unsigned)c * 16u;
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int q = lw * PB + i, plane = q / GB, rg = q % GB;
+                const int r = 16 * rg + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+                voffB[i] = (unsigned)plane * w_plane_b + (unsigned)min(n0 + r, d.N - 1) * 64u + (unsigned)c * 16u;
+            }
+            i_c0 = 0; i_ky = 0; i_kx = 0; i_kt = 0; soffA = 0; soffB = 0;
+            set_tap();
+        };
+        set_tile(i_tile);
+        auto issue_step = [&](int stage) {
+            const unsigned so = (unsigned)(stage * STAGE_B);
+            const unsigned sa = __builtin_amdgcn_readfirstlane(soffA), sb = __builtin_amdgcn_readfirstlane(soffB);     // (wave-uniform by construction)
+#pragma unroll
+            for (int i = 0; i < PA; ++i) lds_dma16(rsrcA, ldsA[i] + so, voffA[i], sa);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) lds_dma16(rsrcW, ldsB[i] + so, voffB[i], sb);
+            if (++i_kt == nkt) { i_tile += G; if (i_tile < ntl) set_tile(i_tile); return; }
+            soffB += w_chunk_b; soffA += a_chunk_b;
+            i_c0 += 32;
+            if (i_c0 >= d.Cin) {
+                i_c0 = 0; soffA = 0;
+                if (++i_kx == d.kw) { i_kx = 0; ++i_ky; }
+                set_tap();
+            }
+        };
+        auto wait_tiles = [&](int tiles) {
+            if (tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        for (int t = 0; t < STAGES && t < total; ++t) issue_step(t);
+        wait_tiles(min(STAGES - 1, total - 1));
+        asm volatile("s_barrier" ::: "memory");
+        int stage = 0;
+        for (int t = 0; t + 1 < total; ++t) {
+            wait_tiles(min(STAGES - 2, total - 2 - t));
+            asm volatile("s_barrier" ::: "memory");
+            if (t + STAGES < total) issue_step(stage);
+            stage = stage == STAGES - 1 ? 0 : stage + 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer waves
+    float* __restrict__ C = d.c + (size_t)bz * d.batch_stride_c;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[1][1], tot;
+    constexpr int KBLK = 8;
+    unsigned offA[2], offB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ch = (2 * j + lh) ^ ((li >> 2) & 3);
+        offA[j] = (unsigned)((wm * 32 + li) * 64 + ch * 16);
+        offB[j] = (unsigned)((BM + wn * 32 + li) * 64 + ch * 16);
+    }
+    bf16x8 fa[2][3], fb[2][3];
+    auto read_set = [&](int nbuf, int so, int nj, int set) {
+        const int ra = set == 0 ? 2 : set == 1 ? 0 : 1, rb = set == 0 ? 0 : set == 1 ? 2 : 1;
+        fa[nbuf][ra] = *reinterpret_cast<const bf16x8*>(sm + so + ra * PLANE_B + offA[nj]);
+        fb[nbuf][rb] = *reinterpret_cast<const bf16x8*>(sm + so + rb * PLANE_B + offB[nj]);
+    };
+    auto prod = [&](int buf, int p, int q, int nbuf, int so, int nj, int set) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][p], fb[buf][q], acc[0][0], 0, 0, 0);
+        if (set >= 0) read_set(nbuf, so, nj, set);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    asm volatile("s_barrier" ::: "memory");         // step 0 is in LDS
+    read_set(0, 0, 0, 0); read_set(0, 0, 0, 1); read_set(0, 0, 0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    auto step_body = [&](auto more_c, int stage, int kt) {       // one K step; stage = (global step) % STAGES, a run-time value here
+        constexpr bool MORE = decltype(more_c)::value;
+        const int so = stage * STAGE_B, sn = (stage == STAGES - 1 ? 0 : stage + 1) * STAGE_B;
+        prod(0, 2, 0, 1, so, 1, 0); prod(0, 0, 2, 1, so, 1, 1); prod(0, 1, 1, 1, so, 1, 2);
+        prod(0, 1, 0, 0, 0, 0, -1); prod(0, 0, 1, 0, 0, 0, -1); prod(0, 0, 0, 0, 0, 0, -1);
+        if (MORE) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            prod(1, 2, 0, 0, sn, 0, 0); prod(1, 0, 2, 0, sn, 0, 1); prod(1, 1, 1, 0, sn, 0, 2);
+        } else {
+            prod(1, 2, 0, 0, 0, 0, -1); prod(1, 0, 2, 0, 0, 0, -1); prod(1, 1, 1, 0, 0, 0, -1);
+        }
+        prod(1, 1, 0, 0, 0, 0, -1); prod(1, 0, 1, 0, 0, 0, -1); prod(1, 0, 0, 0, 0, 0, -1);
+        if ((kt & (KBLK - 1)) == KBLK - 1 && kt + 1 < nkt) {
+            tot = tot + acc[0][0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int stage = 0;
+    for (int ti = 0; ti < nmine; ++ti) {
+        const int idx = w + ti * G;
+        const int m0 = (idx / ntn) * BM, n0 = (idx % ntn) * BN;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; tot[r] = 0.f; }
+        const int nsteps = ti == nmine - 1 ? nkt - 1 : nkt;          // the very last K step of the walk has no successor: peeled
+        for (int kt = 0; kt < nsteps; ++kt) {
+            step_body(st_true{}, stage, kt);
+            stage = stage == STAGES - 1 ? 0 : stage + 1;
+        }
+        if (ti == nmine - 1) step_body(st_false{}, stage, nkt - 1);
+        if (nkt > KBLK) acc[0][0] = acc[0][0] + tot;
+        {
+            // (non-temporal stores for the raw volume -- 64 MiB per sample written once -- were measured: 589 -> 987 us on 8 x 4096 x 4096 x 256;
+            // the default write-back path, which lets the L2 merge the 128-byte row pieces of neighbouring waves, stays)
+            EpiOperands<1, 1> eop;
+            gemm_epilogue_consts<1, 1>(d, eop, n0, wn, li, 1);
+            gemm_epilogue_load<1, 1>(d, eop, m0, n0, wm, wn, li, lh, 1);
+            gemm_epilogue_store<1, 1, false, CT>(d, C, acc, eop, m0, n0, wm, wn, li, lh, 1, 0);
+        }
+    }
+}
+
+template <bool CT>
+__global__ __launch_bounds__(512, 4) void conv_gemm_split3_persist_kernel(const st_gemm_desc d) {
+    conv_gemm_split3_persist_body<CT>(d);
+}
+
 template <int WM, int WN, int TM, int TN, int STAGES, int DIAG = 0>
 __global__ __launch_bounds__(512) void conv_gemm_split3_kernel(const st_gemm_desc d) {
     conv_gemm_split3_body<WM, WN, TM, TN, STAGES, DIAG>(d, (int)blockIdx.x);

@@ -305,6 +305,14 @@ def corr_volume(f1, f2, out):
     return out
 
 
+def corr_volume_split3(f1p, f2p, out12, out21, B, N, Cc):
+    """all-pairs volume(s) from the feature planes (st_corr_volume_split3): f1p / f2p = split3_pack of the [B*N, C] feature rows; out21 may be None."""
+    assert f1p.pstride == f2p.pstride and f1p.rows == f2p.rows
+    check(lib.st_corr_volume_split3(C.c_void_p(f1p.ptr()), C.c_void_p(f2p.ptr()), f1p.pstride, f1p.rows, _pc(out12), _pc(out21) if out21 is not None else None,
+                                    B, N, Cc, _stream()), "st_corr_volume_split3")
+    return out12
+
+
 def corr_volume_both(f1, f2, out12, out21):
     """out12 = f1 . f2^T and out21 = f2 . f1^T (= out12^T) from one launch."""
     B, N, Cc = f1.shape

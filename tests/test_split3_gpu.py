@@ -264,3 +264,50 @@ def test_split3_kernels_do_not_corrupt_their_neighbours(ops):
         torch.cuda.synchronize()
         bad += sum(not torch.equal(r, ref) for r in rs)
     assert bad == 0, f"{bad} of 480 resize launches beside a split3 GEMM were corrupted"
+
+
+@pytest.mark.parametrize("case", ["corr_both", "conv_stride2", "plain_many_tiles"])
+def test_split3_persistent_walk(ops, case):
+    """tile_cfg 37: a workgroup walks several output tiles with one continuous DMA ring (the all-pairs volume with its transposed second store,
+    PatchEmbed's stride-2 6x6 convolution, a plain product with more tiles than workgroup slots): against the fp32 kernel and the fp64 product."""
+    if case == "corr_both":
+        B, N, Cc = 3, 1024, 256
+        f1, f2 = dev(torch.randn(B, N, Cc, generator=g(60))), dev(torch.randn(B, N, Cc, generator=g(61)))
+        v12, v21 = torch.empty(B, N, N, device="cuda"), torch.empty(B, N, N, device="cuda")
+        e12, e21 = torch.empty(B, N, N, device="cuda"), torch.empty(B, N, N, device="cuda")
+        ops.corr_volume_split3(ops.split3_pack(f1.view(B * N, Cc)), ops.split3_pack(f2.view(B * N, Cc)), v12, v21, B, N, Cc)
+        ops.corr_volume_both(f1, f2, e12, e21)
+        torch.cuda.synchronize()
+        ref = f1.double() @ f2.double().transpose(1, 2)
+        scale = ref.pow(2).mean().sqrt()
+        es, ee = (v12.double() - ref).pow(2).mean().sqrt() / scale, (e12.double() - ref).pow(2).mean().sqrt() / scale
+        check("split3_persist_corr_rms_vs_fp64", es.item(), 1.25 * ee.item())
+        assert torch.equal(v21, v12.transpose(1, 2).contiguous())                 # the transposed store carries the same bits
+        v1 = torch.empty(B, N, N, device="cuda")
+        ops.corr_volume_split3(ops.split3_pack(f1.view(B * N, Cc)), ops.split3_pack(f2.view(B * N, Cc)), v1, None, B, N, Cc)
+        torch.cuda.synchronize()
+        assert torch.equal(v1, v12)
+    elif case == "conv_stride2":
+        M, H, W, Cin, N = 40, 16, 16, 32, 64                                       # PatchEmbed's Conv2d(32, 64, 6, 2, 2) on 40 maps: 40 * 64 rows
+        x = dev(torch.randn(M * H * W, Cin, generator=g(62)))
+        w = dev(torch.randn(N, 36 * Cin, generator=g(63)) / 34.0)
+        bias = dev(torch.randn(N, generator=g(64)))
+        geom = (M, H, W, 6, 6, 2, 2, 2, 2, 8, 8)
+        oe, os_ = torch.empty(M * 64, N, device="cuda"), torch.empty(M * 64, N, device="cuda")
+        ops.conv_gemm(x, w, oe, geom=geom, bias=bias)
+        ops.conv_gemm(ops.split3_pack(x), ops.split3_pack(w), os_, geom=geom, bias=bias, tile=37)
+        torch.cuda.synchronize()
+        ref = F.conv2d(x.double().view(M, H, W, Cin).permute(0, 3, 1, 2), w.double().view(N, 6, 6, Cin).permute(0, 3, 1, 2), bias.double(), stride=2, padding=2)
+        ref = ref.permute(0, 2, 3, 1).reshape(-1, N)
+        scale = ref.pow(2).mean().sqrt()
+        check("split3_persist_conv_s2_rms_vs_fp64", ((os_.double() - ref).pow(2).mean().sqrt() / scale).item(), 1.25 * ((oe.double() - ref).pow(2).mean().sqrt() / scale).item())
+    else:
+        M, N, K = 64 * 40, 64 * 30, 160                                            # 1 200 tiles on 512 slots, 5 K steps per tile, ragged walk lengths
+        a, w = dev(torch.randn(M, K, generator=g(65))), dev(torch.randn(N, K, generator=g(66)))
+        oe, os_ = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        ops.conv_gemm(a, w, oe)
+        ops.conv_gemm(ops.split3_pack(a), ops.split3_pack(w), os_, tile=37, act="relu")
+        ops.conv_gemm(a, w, oe, act="relu")
+        torch.cuda.synchronize()
+        ref = (a.double() @ w.double().t()).clamp_min(0)
+        assert ((os_.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6

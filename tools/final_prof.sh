@@ -4,7 +4,7 @@
 # command + trace overlap + per-shape table with PMC traffic + SQ counters of the fused MLP kernel.  Everything lands under gpurun_out/;
 # copy what is to be judged into profiles/.
 export TMPDIR=/tmp
-TAG=${1:-r5}
+TAG=${1:-r6}
 set -x
 python bench.py --no-cpu-baseline 2>gpurun_out/${TAG}_bench.err | grep '^{' > gpurun_out/${TAG}_bench_nocpu.json
 python bench.py --batch 8 --streams 2 --steps 30 --warmup 4 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_batch8.json

@@ -127,7 +127,7 @@ def run_shape(name, make, iters, tiles):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--tiles", default="31,32,33,34")
+    ap.add_argument("--tiles", default="31,32,33,34,37")
     ap.add_argument("--json", default="")
     ap.add_argument("--shapes", default="conv1x5,aggregate,corr")
     a = ap.parse_args()
