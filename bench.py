@@ -121,6 +121,8 @@ def instrumented_step(run_step):
             a_rows = d.M if d.kh * d.kw <= 1 else (d.M // max(1, d.Ho * d.Wo)) * d.H * d.W       # conv: input pixels
             if plan[0] in (5, 6):       # fused row kernels, reported as M x 128 L x 128 / M x 2 hidden x 128: rows in, weights, rows out
                 abytes = 4.0 * (2 * d.M * 128 + d.N * d.K) + (4.0 * d.M * 128 if plan[0] == 6 else 0.0)      # (+ the MLP's residual re-read)
+            elif plan[0] == 9:          # the same block tail on the split3 kernel (st_mlp128_split3): fp32 rows in (+ the projection's residual) and out, weights as three bf16 planes
+                abytes = 4.0 * (3 * d.M * 128) + 6.0 * d.N * d.K
             elif d.split3:              # exact-split operands: three bf16 planes = 6 bytes per element of A and W; C fp32 (unless c_no_f32)
                 abytes = nb * (6.0 * (a_rows * d.Cin + d.N * d.K) + (0.0 if d.c_no_f32 else 4.0 * d.M * d.N))
             else:

@@ -129,7 +129,7 @@ int st_set_gemm_observer(void* callback, void* user);
  *   plan4[0] kernel family (0 skinny_gemm, 1 narrow_conv, 2 conv_gemm_kernel [register-staged], 3 conv_gemm_dma_kernel,
  *            4 rowstream_gemm_kernel, 5 rowchain128_kernel [st_linear_chain128, reported to the observer as M x 128L x 128],
  *            6 rowmlp128_kernel [st_mlp128, reported as M x 2 hidden x 128], 7 patch_c0c2_kernel [st_patch_conv12], 8 conv_gemm_split3_kernel
- *            [st_gemm_desc.split3: tile_cfg 31..36])
+ *            [st_gemm_desc.split3: tile_cfg 31..37], 9 rowmlp128_split3_kernel [st_mlp128_split3])
  *   plan4[1] tile_cfg actually used, plan4[2] split_k actually used, plan4[3] 1 = persistent M walk, 2 / 3 = first / second
  *            member of an st_conv_gemm_pair launch (one dispatch, reported with the second member).
  * Used by tools/gemm_shapes_csv.py to label every launch of a step (profiles/r2_gemm_shapes.csv). */
@@ -195,6 +195,18 @@ typedef struct st_mlp_desc {
 } st_mlp_desc;
 int st_mlp128(const st_mlp_desc* desc, void* stream);
 int st_abi_mlp_desc_size(void);
+/* st_mlp128 on the exact-split contraction (round 6, csrc/mlp_split3.h): every fp32 product of the three GEMMs as six bf16 MFMA
+ * products of operand planes (hi / mid / lo), fp32 accumulation; same operator, same `desc`; accuracy against fp64 that of the fp32 MFMA
+ * chain or better (tests/test_split3_gpu.py); a non-finite activation gives NaN in its row.  The weights are packed ONCE into an image
+ * (one 49-KiB LDS stage per step of the kernel's walk: [wp chunk]* then [w1 chunk | w2 slice | b1 chunk]*):
+ *   st_mlp128_split3_image_bytes(hidden, with_proj, &bytes)  size of the image
+ *   st_mlp128_split3_pack(w1, b1, w2, wp, bp, hidden, image, image_bytes, stream)   wp / bp NULL = no projection
+ *   st_mlp128_split3(desc, image, image_bytes, stream)   desc->w1 / b1 / w2 / bp are not read; desc->wp != NULL <=> the image holds a projection.
+ * plan4[0] = 9; reported to the observer like st_mlp128 with split3 = 1.                                                            */
+int st_mlp128_split3_image_bytes(int32_t hidden, int32_t with_proj, int64_t* bytes);
+int st_mlp128_split3_pack(const float* w1, const float* b1, const float* w2, const float* wp, const float* bp, int32_t hidden, void* image,
+                          int64_t image_bytes, void* stream);
+int st_mlp128_split3(const st_mlp_desc* desc, const void* image, int64_t image_bytes, void* stream);
 
 /* All-pairs correlation volume, MemoryEncoder.corr (encoder.py:359-369):
  *   f1, f2 [B, N, C] channels-last features -> vol [B, N1, N2] = f1 . f2^T (no scaling). */

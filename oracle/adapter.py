@@ -71,12 +71,15 @@ def blend_canvas(homo1, homo2, final):
     return o1, o2, m1o, m2o, blend
 
 
-def forward_test_out(sd, img1, img2, iters=12):
-    """type='test_out' (flowHomoAdpater.py:197-377); batch must be 1 (shared canvas)."""
+def forward_test_out(sd, img1, img2, iters=12, motion=None):
+    """type='test_out' (flowHomoAdpater.py:197-377); batch must be 1 (shared canvas).
+
+    ``motion`` (test hook, as in forward_test_eval): corner offsets [B,4,2] of the 512 x 512 pair to use instead of the homography net's own."""
     B, _, ih, iw = img1.shape
     hw, fw = W(sd, "homo_backbone."), W(sd, "flow_backbone.")
     a512, b512 = geom.resize512(img1), geom.resize512(img2)                          # :204-205
-    motion = homo_offsets(hw, a512, b512)
+    if motion is None:
+        motion = homo_offsets(hw, a512, b512)
     src = _corners(B, 512., 512.)
     H512 = geom.dlt4(src, src + motion)                                              # :216
     out_H = geom.homo_transformer(torch.cat([b512, torch.ones_like(b512)], 1),

@@ -35,7 +35,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_split3.h"), os.path.join(HERE, "..", "include", "stitch_gfx950.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_split3.h"), os.path.join(CSRC, "mlp_split3.h"), os.path.join(HERE, "..", "include", "stitch_gfx950.h")]
     objs, jobs = [], []
     os.makedirs(os.path.join(CSRC, "_obj"), exist_ok=True)
     for src, extra in SOURCES.items():

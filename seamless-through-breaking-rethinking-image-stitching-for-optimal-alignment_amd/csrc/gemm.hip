@@ -1554,6 +1554,85 @@ extern "C" int st_mlp128(const st_mlp_desc* desc, void* stream) {
     return ST_OK;
 }
 
+#include "mlp_split3.h"
+
+// bytes of the weight image of st_mlp128_split3 (one 49-KiB LDS stage image per step of the walk)
+static int64_t mlp_split3_image_bytes(int32_t hidden, bool with_proj) {
+    if (hidden < 32 || hidden > 2048 || (hidden & 31)) return 0;
+    return (int64_t)((with_proj ? 4 : 0) + hidden / 32) * MS3_STAGE_B;
+}
+extern "C" int st_mlp128_split3_image_bytes(int32_t hidden, int32_t with_proj, int64_t* bytes) {
+    if (!bytes) return ST_EINVAL;
+    *bytes = mlp_split3_image_bytes(hidden, with_proj != 0);
+    return *bytes ? ST_OK : ST_EINVAL;
+}
+
+extern "C" int st_mlp128_split3_pack(const float* w1, const float* b1, const float* w2, const float* wp, const float* bp, int32_t hidden, void* image,
+                                     int64_t image_bytes, void* stream) {
+    if (!w1 || !b1 || !w2 || !image || hidden < 32 || hidden > 2048 || (hidden & 31) || ((uintptr_t)image & 15) || (!wp && bp)) return ST_EINVAL;
+    if (image_bytes < mlp_split3_image_bytes(hidden, wp != nullptr)) return ST_EINVAL;
+    const int steps = (wp ? 4 : 0) + hidden / 32;
+    hipLaunchKernelGGL(mlp_split3_pack_kernel, dim3(5, steps), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, wp, bp, (int)hidden, (unsigned char*)image);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// st_mlp128 on the exact-split contraction (csrc/mlp_split3.h).  `desc` as for st_mlp128 -- w1 / b1 / w2 / bp are not read (the image holds them),
+// wp != NULL says that the image was packed WITH the projection; b2 is read.
+extern "C" int st_mlp128_split3(const st_mlp_desc* desc, const void* image, int64_t image_bytes, void* stream) {
+    if (!desc || !image) return ST_EINVAL;
+    const st_mlp_desc& d = *desc;
+    if (!d.a || !d.out || !d.b2 || d.M <= 0 || d.hidden < 32 || d.hidden > 2048 || (d.hidden & 31) || d.lda < 128 || d.ldo < 128 || (d.lda & 3) ||
+        (d.ldo & 3) || d.reserved != 0 || (int64_t)d.M * (d.lda > d.ldo ? d.lda : d.ldo) >= ((int64_t)1 << 40))
+        return ST_EINVAL;
+    if ((((uintptr_t)d.a | (uintptr_t)d.out | (uintptr_t)d.b2 | (uintptr_t)image) & 15)) return ST_EINVAL;
+    if (d.res && (d.ld_res < 128 || (d.ld_res & 3) || ((uintptr_t)d.res & 15))) return ST_EINVAL;
+    if (d.a == d.out) return ST_EINVAL;
+    if (!d.wp && (d.bp || d.res0)) return ST_EINVAL;
+    if (d.res0 && (d.ld_res0 < 128 || (d.ld_res0 & 3) || ((uintptr_t)d.res0 & 15) || d.res0 == d.out)) return ST_EINVAL;
+    const int64_t need = mlp_split3_image_bytes(d.hidden, d.wp != nullptr);
+    if (!need) return ST_EINVAL;
+    if (image_bytes < need || need >= ((int64_t)1 << 31)) return ST_EINVAL;
+    const int nblk = (d.M + 31) / 32;
+    int G = (nblk + MS3_NWAVES - 1) / MS3_NWAVES;
+    if (G > 256) G = 256;                                       // 147 KB of LDS: one workgroup per CU
+    const size_t lds = (size_t)3 * MS3_STAGE_B;
+    // timing experiment (tools/mlp_split3_probe.py --diag): ST_MLP3_DIAG=1 runs the instrumented instance, waits for it and prints per-phase cycle sums of wave 0
+    static const int diag = [] { const char* e = getenv("ST_MLP3_DIAG"); return e ? atoi(e) : 0; }();
+    if (diag) {
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf && hipHostMalloc((void**)&dbuf, 256 * 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return ST_EINVAL;      // pinned: the kernel writes it, the host reads it after the sync
+        auto kd = d.wp ? rowmlp128_split3_kernel<true, true> : rowmlp128_split3_kernel<false, true>;
+        (void)hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kd, dim3(G), dim3(64 * MS3_NWAVES), lds, (hipStream_t)stream, d, (const unsigned char*)image, (unsigned)need, dbuf);
+        ST_CHECK_LAUNCH();
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return ST_EINVAL;
+        const unsigned long long* h = dbuf;
+        double s8[8] = {0}, sum = 0;
+        for (int b = 0; b < G; ++b) for (int i = 0; i < 8; ++i) s8[i] += (double)h[8 * b + i] / G;
+        for (int i = 0; i < 8; ++i) sum += s8[i];
+        fprintf(stderr, "mlp_split3 diag (mean s_memtime cycles of wave 0 over %d workgroups): syncs %.0f  load+split %.0f  projection %.0f  LN+split %.0f  first fc1 %.0f  phase1 %.0f  phase2 %.0f  last+epilogue %.0f  sum %.0f\n",
+                G, s8[0], s8[1], s8[2], s8[3], s8[4], s8[5], s8[6], s8[7], sum);
+        return ST_OK;
+    }
+    auto kern = d.wp ? rowmlp128_split3_kernel<true> : rowmlp128_split3_kernel<false>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    st_gemm_observer_fn obs = g_observer;
+    st_gemm_desc od;
+    if (obs) {
+        memset(&od, 0, sizeof(od));
+        od.a = d.a; od.c = d.out; od.w = (const float*)image;
+        od.M = d.M; od.N = 2 * d.hidden + (d.wp ? 128 : 0); od.K = 128; od.H = 1; od.W = d.M; od.Cin = 128; od.ldx = d.lda; od.ldc = d.ldo; od.ldw = 128;
+        od.kh = od.kw = od.sh = od.sw = 1; od.Ho = 1; od.Wo = d.M; od.batch = 1; od.alpha = 1.f; od.split3 = 1;
+        obs(&od, stream, 0, g_observer_user);
+    }
+    g_last_plan[0] = 9; g_last_plan[1] = 38; g_last_plan[2] = 1; g_last_plan[3] = 1;
+    hipLaunchKernelGGL(kern, dim3(G), dim3(64 * MS3_NWAVES), lds, (hipStream_t)stream, d, (const unsigned char*)image, (unsigned)need, (unsigned long long*)nullptr);
+    if (obs) obs(&od, stream, 1, g_observer_user);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 // split-K tail: sum the K-slice slabs [split][M][N] in slice order (deterministic) + epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const st_gemm_desc d) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -49,6 +49,7 @@ FUSE_PE = os.environ.get("ST_FUSE_PE", "1") != "0"              # PatchEmbed c0 
 assert not (SPLIT3 and FORK_ENC), "ST_FORK_ENC is an fp32-path experiment"
 S3_PAIR = os.environ.get("ST_S3_PAIR", "1") != "0"
 S3_PE = os.environ.get("ST_S3_PE", "1") != "0"                 # PatchEmbed's third convolution on planes
+S3_MLP = os.environ.get("ST_S3_MLP", "1") != "0"               # the C = 128 block tails (st_mlp128) on the split3 kernel (st_mlp128_split3, weights packed into its image once)
 S3_AGG = os.environ.get("ST_S3_AGG", "0") == "1"               # GMA aggregate on planes (measured equal to the fp32 kernel in the chain: HBM-bound; default off)
 S3_OFF = int(os.environ.get("ST_S3_OFF", "0"))     # bisecting aid: bit 1 mask-head conv, 2 flow-head conv, 8 GRU, 16 motion conv, 32 conv pair back on the fp32 kernels
 _SIDE = {}
@@ -99,6 +100,12 @@ class FlowFormer(ParamTree):
             b = p.get(name + ".bias")
             return pack_conv(p[name + ".weight"], cin_pad), (b.contiguous() if b is not None else None)
 
+        def mlp_image(fc1_ln, fc2, proj):
+            """the split3 image of a block tail (projection + LayerNorm-folded fc1 + fc2), or None: CPU weights (tests of the pack layouts), switch off"""
+            if not (SPLIT3 and S3_MLP and FUSE_LN and FUSE_MLP and FUSE_PROJ and fc1_ln[0].is_cuda and fc1_ln[0].shape[1] == 128 and proj[0].shape == (128, 128)):
+                return None
+            return ops.mlp128_split3_pack(fc1_ln[0], fc1_ln[1], fc2[0], proj=(proj[0], proj[1]))
+
         def twins(prefix):
             t = {}
             t["pe0"] = conv(prefix + "patch_embeds.0.proj", 4)
@@ -115,6 +122,7 @@ class FlowFormer(ParamTree):
                 if C == 128:
                     t[f"l{s}"]["qkv_ln"] = ops.fold_layernorm(*t[f"l{s}"]["n1"], qkv_w, qkv_b)
                     t[f"l{s}"]["fc1_ln"] = ops.fold_layernorm(*t[f"l{s}"]["n2"], *t[f"l{s}"]["fc1"])
+                    t[f"l{s}"]["mlp_s3"] = mlp_image(t[f"l{s}"]["fc1_ln"], t[f"l{s}"]["fc2"], t[f"l{s}"]["proj"])
                 w9 = p[prefix + f"pos_block.{s}.proj.0.weight"].reshape(C, 9).t().contiguous()
                 t[f"peg{s}"] = (w9, p[prefix + f"pos_block.{s}.proj.0.bias"].contiguous())
                 t[f"g{s}"] = dict(n1=lin(b1 + "norm1"), q=lin(b1 + "attn.q"), kv=lin(b1 + "attn.kv"), sr=conv(b1 + "attn.sr"),
@@ -122,6 +130,7 @@ class FlowFormer(ParamTree):
                                   fc1=lin(b1 + "mlp.fc1"), fc2=lin(b1 + "mlp.fc2"))
                 if C == 128:
                     t[f"g{s}"]["fc1_ln"] = ops.fold_layernorm(*t[f"g{s}"]["n2"], *t[f"g{s}"]["fc1"])
+                    t[f"g{s}"]["mlp_s3"] = mlp_image(t[f"g{s}"]["fc1_ln"], t[f"g{s}"]["fc2"], t[f"g{s}"]["proj"])
             return t
 
         pk["fnet"] = twins("memory_encoder.feat_encoder.svt.")
@@ -192,6 +201,8 @@ class FlowFormer(ParamTree):
             vert[-1]["lqkv_ln"] = ops.fold_layernorm(*vert[-1]["ln1"], vert[-1]["lqkv"])
             vert[-1]["lfc1_ln"] = ops.fold_layernorm(*vert[-1]["ln2"], *vert[-1]["lfc1"])
             vert[-1]["gfc1_ln"] = ops.fold_layernorm(*vert[-1]["gn2"], *vert[-1]["gfc1"])
+            vert[-1]["lmlp_s3"] = mlp_image(vert[-1]["lfc1_ln"], vert[-1]["lfc2"], vert[-1]["lproj"])
+            vert[-1]["gmlp_s3"] = mlp_image(vert[-1]["gfc1_ln"], vert[-1]["gfc2"], vert[-1]["gproj"])
         pk["vert"] = vert
         m = "memory_decoder."
         Q = HP["query_latent_dim"]
@@ -245,7 +256,7 @@ class FlowFormer(ParamTree):
 
     # ================================================================== shared blocks
     @staticmethod
-    def _mlp(x, n2, fc1, fc2, eps, out=None, fc1_ln=None, extra_res=None, proj=None):
+    def _mlp(x, n2, fc1, fc2, eps, out=None, fc1_ln=None, extra_res=None, proj=None, image=None):
         """x + fc2(GELU(fc1(LN(x)))) [+ extra_res] (timm Mlp inside Block, twins.py:785-790).  proj = (att, (w, b), res): x is the Block's
         attention branch x = att @ w^T + b + res (twins.py:622-623 / 676-677), computed by the same launch when the rows are 128 wide."""
         if proj is not None:
@@ -254,7 +265,7 @@ class FlowFormer(ParamTree):
             if (fc1_ln is not None and FUSE_LN and FUSE_MLP and FUSE_PROJ and att.shape[1] == 128 and pw.is_contiguous()
                     and fc2[0].is_contiguous() and fc1_ln[0].is_contiguous() and pw.data_ptr() % 16 == 0 and pb.data_ptr() % 16 == 0):
                 o = _new(att.shape[0], 128, dev) if out is None else out
-                return ops.mlp128(att, o, fc1_ln[0], fc1_ln[1], fc2[0], fc2[1], ln_eps=eps, res=extra_res, proj=(pw, pb, pres))
+                return ops.mlp128(att, o, fc1_ln[0], fc1_ln[1], fc2[0], fc2[1], ln_eps=eps, res=extra_res, proj=(pw, pb, pres), image=image)
             x = _new(att.shape[0], att.shape[1], dev)
             ops.conv_gemm(att, pw, x, bias=pb, aux0=pres)
         dev = x.device
@@ -300,7 +311,7 @@ class FlowFormer(ParamTree):
             att = _new(N, C, dev)
             ops.window_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], H * W * 3 * C, 3 * C, *L["pads"], att,
                                  H * W * C, C, B, H, W, hd, C // hd, 7, (C // hd) ** -0.5)
-            x2 = self._mlp(None, L["n2"], L["fc1"], L["fc2"], 1e-6, fc1_ln=L.get("fc1_ln"), proj=(att, L["proj"], x))
+            x2 = self._mlp(None, L["n2"], L["fc1"], L["fc2"], 1e-6, fc1_ln=L.get("fc1_ln"), proj=(att, L["proj"], x), image=L.get("mlp_s3"))
             # ---- PEG (twins.py:793-808)
             x3 = _new(N, C, dev)
             ops.dwconv3x3_residual(x2, t[f"peg{s}"][0], t[f"peg{s}"][1], x3, B, H, W, C)
@@ -319,7 +330,7 @@ class FlowFormer(ParamTree):
             ops.conv_gemm(xsn, Gk["kv"][0], kv, bias=Gk["kv"][1])
             ops.attention_kvlds(q, (H * W * C, C), kv[:, :C], (Nk * 2 * C, 2 * C), kv[:, C:], (Nk * 2 * C, 2 * C), att,
                                 (H * W * C, C), B, hd, H * W, Nk, C // hd, (C // hd) ** -0.5)
-            x = self._mlp(None, Gk["n2"], Gk["fc1"], Gk["fc2"], 1e-6, fc1_ln=Gk.get("fc1_ln"), proj=(att, Gk["proj"], x3))
+            x = self._mlp(None, Gk["n2"], Gk["fc1"], Gk["fc2"], 1e-6, fc1_ln=Gk.get("fc1_ln"), proj=(att, Gk["proj"], x3), image=Gk.get("mlp_s3"))
         return x, H, W
 
     # ------------------------------------------------------------------ cost-volume encoder
@@ -462,7 +473,7 @@ class FlowFormer(ParamTree):
             sl = slice(b * N * nl, (b + 1) * N * nl)
             ops.window_attention(q[sl], k[sl], v[sl], 3 * C, nl * 3 * C, qp, kp, vp, att[sl], C, nl * C, nl, H1, W1, 8, 16, 7,
                                  16 ** -0.5)
-        x2 = self._mlp(None, V["ln2"], V["lfc1"], V["lfc2"], 1e-5, fc1_ln=V["lfc1_ln"], proj=(att, V["lproj"], x))
+        x2 = self._mlp(None, V["ln2"], V["lfc1"], V["lfc2"], 1e-5, fc1_ln=V["lfc1_ln"], proj=(att, V["lproj"], x), image=V.get("lmlp_s3"))
         # ---------------- global block
         ops.layernorm(x2, V["gn1"][0], V["gn1"][1], y, 1e-5)
         z = _new(B * N, Cq, dev)
@@ -502,7 +513,7 @@ class FlowFormer(ParamTree):
             kb = kv[b * Nk:]
             ops.attention_kvlds(q[sl], (C, nl * C), kb[:, :C], (B * Nk * 2 * C, 2 * C), kb[:, C:], (B * Nk * 2 * C, 2 * C),
                                 att[sl], (C, nl * C), nl, 8, N, Nk, 16, 16 ** -0.5)
-        return self._mlp(None, V["gn2"], V["gfc1"], V["gfc2"], 1e-5, fc1_ln=V["gfc1_ln"], extra_res=extra_res, proj=(att, V["gproj"], x2))
+        return self._mlp(None, V["gn2"], V["gfc1"], V["gfc2"], 1e-5, fc1_ln=V["gfc1_ln"], extra_res=extra_res, proj=(att, V["gproj"], x2), image=V.get("gmlp_s3"))
 
     def _cost_encoder(self, cost_maps, ctx, B, H1, W1, ctx_ready=None):
         """CostPerceiverEncoder.forward (encoder.py:258-287) -> cost memory rows [B*N*8, 128]."""

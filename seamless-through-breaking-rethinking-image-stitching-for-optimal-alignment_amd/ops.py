@@ -271,7 +271,22 @@ def linear_chain128(a, out, layers):
     return out
 
 
-def mlp128(a, out, w1, b1, w2, b2, ln_eps=None, res=None, proj=None):
+def mlp128_split3_pack(w1, b1, w2, proj=None):
+    """weights of one st_mlp128 -> the image st_mlp128_split3 streams (uint8 tensor; pack once per weight load).  proj = (wp, bp or None)."""
+    hidden = w1.shape[0]
+    assert w1.shape == (hidden, 128) and w2.shape == (128, hidden) and w1.is_contiguous() and w2.is_contiguous() and b1.shape == (hidden,)
+    nb = C.c_int64(0)
+    check(lib.st_mlp128_split3_image_bytes(hidden, 1 if proj is not None else 0, C.byref(nb)), "st_mlp128_split3_image_bytes")
+    img = torch.empty(nb.value, dtype=torch.uint8, device=w1.device)
+    wp, bp = proj if proj is not None else (None, None)
+    if wp is not None:
+        assert wp.shape == (128, 128) and wp.is_contiguous()
+    check(lib.st_mlp128_split3_pack(_p(w1), _p(b1), _p(w2), _p(wp) if wp is not None else None, _p(bp) if bp is not None else None, hidden,
+                                    C.c_void_p(img.data_ptr()), nb.value, _stream()), "st_mlp128_split3_pack")
+    return img
+
+
+def mlp128(a, out, w1, b1, w2, b2, ln_eps=None, res=None, proj=None, image=None):
     """out = x + (GELU(LN(x) @ w1^T + b1) @ w2^T + b2) [+ res] over 128-wide rows in one launch (st_mlp128: the hidden activations stay
     on the CU).  x = a, or with proj = (wp [128,128], bp or None, res0 or None): x = a @ wp^T + bp + res0 (the Block's attention output
     projection + residual in the same launch).  ln_eps None = no LayerNorm (otherwise without affine: fold gamma / beta into w1 / b1)."""
@@ -294,6 +309,9 @@ def mlp128(a, out, w1, b1, w2, b2, ln_eps=None, res=None, proj=None):
         if res0 is not None:
             assert res0.shape == a.shape
             d.res0, d.ld_res0 = res0.data_ptr(), _ld(res0)
+    if image is not None:                                       # the exact-split kernel on the packed image (mlp128_split3_pack)
+        check(lib.st_mlp128_split3(C.byref(d), C.c_void_p(image.data_ptr()), image.numel(), _stream()), "st_mlp128_split3")
+        return out
     check(lib.st_mlp128(C.byref(d), _stream()), "st_mlp128")
     return out
 

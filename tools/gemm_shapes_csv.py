@@ -22,7 +22,7 @@ import sys
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 
 FAMILY = {0: "skinny_gemm_kernel", 1: "narrow_conv_kernel", 2: "conv_gemm_kernel", 3: "conv_gemm_dma_kernel", 4: "rowstream_gemm_kernel", 5: "rowchain128_kernel",
-          6: "rowmlp128_kernel", 7: "patch_c0c2_kernel", 8: "conv_gemm_split3_kernel"}
+          6: "rowmlp128_kernel", 7: "patch_c0c2_kernel", 8: "conv_gemm_split3_kernel", 9: "rowmlp128_split3_kernel"}
 PEAK = 157.3
 
 
@@ -64,6 +64,10 @@ def timing_pass(out_csv, launches_json=None, profile_only=False):
             # fused row kernels (reported as M x 128 L x 128 / M x 2 hidden x 128): the intermediate activations never move --
             # A rows in, weights, 128-wide rows out (+ the residual rows re-read by the MLP kernel)
             alg = 4.0 * (d.M * 128 + d.M * 128) + w_bytes + (4.0 * d.M * 128 if plan[0] == 6 else 0.0)
+        elif plan[0] == 9:
+            # the block tail on the split3 kernel: fp32 rows in (+ the projection's residual rows) and out, weights as three bf16 planes
+            w_bytes = 6.0 * d.N * d.K
+            alg = 4.0 * 3 * d.M * 128 + w_bytes
         elif d.split3:
             # exact-split operands: three bf16 planes = 6 bytes per element of A and W
             w_bytes = 6.0 * nb * d.N * d.K
