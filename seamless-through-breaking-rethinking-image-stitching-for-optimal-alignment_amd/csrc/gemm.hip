@@ -2102,6 +2102,20 @@ static int launch_split3(const st_gemm_desc& d, hipStream_t s) {
     return ST_OK;
 }
 
+// two consumer groups per workgroup (KPAR = 2, csrc/gemm_split3.h): 768 threads, same tiles, same ring
+template <int WM, int WN, int TM, int TN, int STAGES>
+static int launch_split3_kpar(const st_gemm_desc& d, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    const int batch = d.batch > 0 ? d.batch : 1;
+    const size_t lds = (size_t)STAGES * 3 * (BM + BN) * 64;
+    void (*k)(const st_gemm_desc) = conv_gemm_split3_kpar_kernel<WM, WN, TM, TN, STAGES>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(ntm * ntn, 1, batch), dim3(768), lds, s, d);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 // checks + buffer extents of a split3 descriptor (shared by st_conv_gemm and st_conv_gemm_pair)
 static int split3_prepare(const st_gemm_desc* desc, st_gemm_desc& d) {
     d = *desc;
@@ -2158,12 +2172,23 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
     if (d.c_t) cfg = 37;
     static const int tile_env = [] { const char* e = getenv("ST_SPLIT3_TILE"); return e ? atoi(e) : 0; }();      // experiments: force one tile configuration
     if (tile_env && d.tile_cfg == 0 && !d.c_t) cfg = tile_env;
-    static const int bms[8] = {0, 128, 128, 64, 64, 128, 64, 64}, bns[8] = {0, 128, 64, 128, 64, 64, 64, 64};
-    if (cfg < 31 || cfg > 37) return ST_EINVAL;
+    // two consumer groups per workgroup (csrc/gemm_split3.h KPAR; tile_cfg 39: 64x64 tiles, 38: 128x64) for a launch of exactly one 64x64 tile per CU and
+    // a long K -- the N = 128 shapes at M = 8 192 (SepConvGRU's q convolutions, the motion encoder's 126-channel conv).  Measured (tools/split3_probe.py,
+    // 8192 x 128 x 1920): 23.9 us against 29.1 for the four-consumer tile and 33.9 + a 7.4 us reducer launch for the split-K-2 form it replaces.  The
+    // 128x64 form (bit 1 of ST_SPLIT3_KPAR) is SLOWER than its four-consumer twin on the N = 256 shapes (47.7 against 42.7 us): three waves per SIMD and
+    // twelve waves per barrier cost more than the second MFMA issuer returns there.  ST_SPLIT3_KPAR=0: off.
+    static const int kpar_env = [] { const char* e = getenv("ST_SPLIT3_KPAR"); return e ? atoi(e) : 2; }();
+    if (kpar_env && d.tile_cfg == 0 && !tile_env && batch == 1 && d.split_k <= 1 && d.K >= 1024) {
+        if ((kpar_env & 1) && cfg == 32 && (long)((d.M + 127) / 128) * ((d.N + 63) / 64) <= 512) cfg = 38;
+        else if ((kpar_env & 2) && cfg == 34 && ntl64 == 256) cfg = 39;
+    }
+    static const int bms[10] = {0, 128, 128, 64, 64, 128, 64, 64, 128, 64}, bns[10] = {0, 128, 64, 128, 64, 64, 64, 64, 64, 64};
+    if (cfg < 31 || cfg > 39) return ST_EINVAL;
+    if (cfg >= 38 && (d.split_k > 1 || batch != 1)) return ST_EINVAL;
     if (cfg == 37 && (d.a2 || d.split_k > 1)) return ST_EINVAL;
     const long tiles = (long)((d.M + bms[cfg - 30] - 1) / bms[cfg - 30]) * ((d.N + bns[cfg - 30] - 1) / bns[cfg - 30]) * batch;
     int split = d.split_k;
-    if (cfg == 37) split = 1;
+    if (cfg >= 37) split = 1;
     if (split == 0) {
         split = 1;
         if (batch == 1 && d.workspace && d.K >= 512 && tiles < 256) split = (int)((256 + tiles - 1) / tiles);
@@ -2202,6 +2227,8 @@ static int conv_gemm_split3_launch(const st_gemm_desc* desc, void* stream) {
         return ST_OK;
     }
     switch (cfg) {
+        case 38: return launch_split3_kpar<2, 2, 2, 1, 4>(d, s);
+        case 39: return launch_split3_kpar<2, 2, 1, 1, 4>(d, s);
         case 31: return launch_split3<2, 2, 2, 2, 3>(d, s);
         case 32: return launch_split3<2, 2, 2, 1, 4>(d, s);
         case 33: return launch_split3<2, 2, 1, 2, 4>(d, s);

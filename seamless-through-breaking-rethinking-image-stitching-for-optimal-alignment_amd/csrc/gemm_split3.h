@@ -50,9 +50,15 @@ __global__ __launch_bounds__(256) void split3_pack_kernel(const float* __restric
 }
 
 // DIAG (timing experiments only, results are garbage): 1 = consumers skip the MFMAs (ingest alone), 2 = loaders skip the DMA (reads + MFMAs alone)
-template <int WM, int WN, int TM, int TN, int STAGES, int DIAG = 0>
+// KPAR = 2: EIGHT consumer waves (768-thread workgroups, three waves per SIMD): waves 0-3 take the first 16-k half of every 32-k step, waves 4-7 the
+// second half, on the same 32 x 32 (x TM x TN) sub-tiles; the second group's accumulators cross LDS once, behind the K loop, and the first group
+// runs the epilogue.  A single consumer wave per SIMD issues one v_mfma_f32_32x32x16_bf16 per 32 cycles at best (tools/probes/mfma_bf16_chain.hip)
+// and, with 128 x 64 tiles at one workgroup per CU, that is what bounds the loop (MFMA-only 35 us against DMA-only 29 us on the 1x5 conv); the
+// decoder's M = 8 192 shapes have no second tile to give the CU, so the K dimension is what two waves of a SIMD can share.
+template <int WM, int WN, int TM, int TN, int STAGES, int DIAG = 0, int KPAR = 1>
 __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, const int block_id) {
-    static_assert(WM * WN == 4, "4 consumer waves (+ 4 loader waves)");
+    static_assert(WM * WN == 4, "4 consumer waves per K half (+ 4 loader waves)");
+    static_assert(KPAR == 1 || KPAR == 2, "one or two consumer groups");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, ROWS = BM + BN;
     constexpr int PLANE_B = ROWS * 64, STAGE_B = 3 * PLANE_B;       // bytes
     constexpr int GA = BM / 16, GB = BN / 16;                       // 16-row groups (1-KiB pieces) per plane
@@ -85,9 +91,9 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
 
     unsigned long long sr_entry = 0;
     if (DIAG == 4) sr_entry = __builtin_amdgcn_s_memrealtime();
-    if (wave >= 4) {
+    if (wave >= 4 * KPAR) {
         // ------------------------------------------------------------------ loader waves
-        const int lw = wave - 4;
+        const int lw = wave - 4 * KPAR;
         const char* A = reinterpret_cast<const char*>(d.a) + (size_t)bz * d.batch_stride_a * 2;
         const char* A2 = d.a2 ? reinterpret_cast<const char*>(d.a2) + (size_t)bz * d.batch_stride_a * 2 : A;
         const char* Wt = reinterpret_cast<const char*>(d.w) + (size_t)bz * d.batch_stride_w * 2;
@@ -173,7 +179,8 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
 
     // ---------------------------------------------------------------------- consumer waves
     float* __restrict__ C = d.c + (size_t)bz * d.batch_stride_c;
-    const int wm = wave / WN, wn = wave % WN;
+    const int grp = KPAR == 2 ? wave >> 2 : 0, cw = KPAR == 2 ? wave & 3 : wave;
+    const int wm = cw / WN, wn = cw % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     f32x16 acc[TM][TN], tot[TM][TN];
@@ -193,6 +200,111 @@ __device__ __forceinline__ void conv_gemm_split3_body(const st_gemm_desc& d, con
         const int ch = (2 * j + lh) ^ ((li >> 2) & 3);
         pa[j] = sm + (wm * TM * 32 + li) * 64 + ch * 16;
         pb[j] = sm + (BM + wn * TN * 32 + li) * 64 + ch * 16;
+    }
+    if constexpr (KPAR == 2) {
+        // ---- two consumer groups: this wave owns 16-k half `grp` of every K step.  Fragments of step t + 1 are requested under the first three
+        // products of step t (one whole step ahead of their use); the barrier of step t + 1 comes once they have all returned.
+        bf16x8 ga[2][3][TM], gb[2][3][TN];
+        const int chg = (2 * grp + lh) ^ ((li >> 2) & 3);        // (computed here, not selected from pa[] / pb[]: a run-time select loses the LDS address space -> flat loads)
+        const char* const qa = sm + (wm * TM * 32 + li) * 64 + chg * 16;
+        const char* const qb = sm + (BM + wn * TN * 32 + li) * 64 + chg * 16;
+        auto kread = [&](int nbuf, int nstage, int set) {
+            const int ra = set == 0 ? 2 : set == 1 ? 0 : 1, rb = set == 0 ? 0 : set == 1 ? 2 : 1;
+#pragma unroll
+            for (int r = 0; r < TM; ++r) ga[nbuf][ra][r] = *reinterpret_cast<const bf16x8*>(qa + nstage * STAGE_B + ra * PLANE_B + r * 2048);
+#pragma unroll
+            for (int r = 0; r < TN; ++r) gb[nbuf][rb][r] = *reinterpret_cast<const bf16x8*>(qb + nstage * STAGE_B + rb * PLANE_B + r * 2048);
+        };
+        auto kprod = [&](int buf, int nbuf, int p, int q, int nstage, int set) {
+            const int ra = set == 0 ? 2 : set == 1 ? 0 : 1, rb = set == 0 ? 0 : set == 1 ? 2 : 1;
+            constexpr int NM = TM * TN, NR = TM + TN;
+            int issued = 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[buf][p][i], gb[buf][q][jn], acc[i][jn], 0, 0, 0);
+                    if (set >= 0) {
+                        const int upto = ((i * TN + jn + 1) * NR + NM - 1) / NM;
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+                            if (r >= issued && r < upto) {
+                                if (r < TM) ga[nbuf][ra][r] = *reinterpret_cast<const bf16x8*>(qa + nstage * STAGE_B + ra * PLANE_B + r * 2048);
+                                else gb[nbuf][rb][r - TM] = *reinterpret_cast<const bf16x8*>(qb + nstage * STAGE_B + rb * PLANE_B + (r - TM) * 2048);
+                            }
+                        issued = upto;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        };
+        constexpr bool EPI_AHEAD2 = TM * TN == 1;
+        EpiOperands<TM, TN> eop2;
+        if (EPI_AHEAD2 && grp == 0) {
+            gemm_epilogue_consts<TM, TN>(d, eop2, n0, wn, li, split);
+            gemm_epilogue_load<TM, TN>(d, eop2, m0, n0, wm, wn, li, lh, split);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_barrier" ::: "memory");                 // tile 0 is in LDS
+        kread(0, 0, 0); kread(0, 0, 1); kread(0, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        auto kstep = [&](auto more_c, int buf, int nbuf, int s, int t, bool more_rt) {
+            constexpr bool MORE = decltype(more_c)::value;
+            if (MORE || more_rt) {
+                // the fragments of step t have returned (lgkmcnt(0)): nobody reads stage s any more; step t + 1 has landed everywhere
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                kprod(buf, nbuf, 2, 0, (s + 1) % STAGES, 0); kprod(buf, nbuf, 0, 2, (s + 1) % STAGES, 1); kprod(buf, nbuf, 1, 1, (s + 1) % STAGES, 2);
+            } else {
+                kprod(buf, nbuf, 2, 0, 0, -1); kprod(buf, nbuf, 0, 2, 0, -1); kprod(buf, nbuf, 1, 1, 0, -1);
+            }
+            kprod(buf, nbuf, 1, 0, 0, -1); kprod(buf, nbuf, 0, 1, 0, -1); kprod(buf, nbuf, 0, 0, 0, -1);
+            if ((t & (KBLK - 1)) == KBLK - 1 && (MORE || more_rt)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        tot[i][j] = tot[i][j] + acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        static_assert(STAGES % 2 == 0, "the fragment buffers alternate with the steps: an even ring keeps (stage, buffer) literal in the unrolled turn");
+        int tb = 0;
+        for (; tb + STAGES < ntiles; tb += STAGES) {
+#pragma unroll
+            for (int s = 0; s < STAGES; ++s) kstep(st_true{}, s & 1, (s & 1) ^ 1, s, tb + s, true);
+        }
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s)
+            if (tb + s < ntiles) kstep(st_false{}, s & 1, (s & 1) ^ 1, s, tb + s, tb + s + 1 < ntiles);
+        if (ntiles > KBLK) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] + tot[i][j];
+        }
+        // the ring is dead (every DMA has landed, every fragment read has returned before the last barrier): the second group's partial tiles cross it
+        float* const red = reinterpret_cast<float*>(sm) + (size_t)cw * (TM * TN * 16 * 64) + lane;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();                                        // (the loader waves have left: the barrier counts the waves that are still alive)
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 64];
+        if (EPI_AHEAD2) gemm_epilogue_store<TM, TN, false, false>(d, C, acc, eop2, m0, n0, wm, wn, li, lh, split, kz);
+        else gemm_tile_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, li, lh, split, kz);
+        return;
     }
     // (Measured and dropped, round 6, 1x5 conv 8192 x 256 x 1920 on 64x64 tiles: a third fragment buffer so that both 16-k steps of the next
     // tile are requested right behind the barrier -- 44.5 us either way; two alternating accumulators per sub-tile -- 33.1 vs 33.6 us MFMA-only;
@@ -497,6 +609,11 @@ __global__ __launch_bounds__(512) void conv_gemm_split3_kernel(const st_gemm_des
     conv_gemm_split3_body<WM, WN, TM, TN, STAGES, DIAG>(d, (int)blockIdx.x);
 }
 // the 64x64 configuration lives on TWO workgroups per CU (72 KB of LDS each): 4 waves per SIMD, so at most 128 registers per wave
+template <int WM, int WN, int TM, int TN, int STAGES>
+__global__ __launch_bounds__(768, 1) void conv_gemm_split3_kpar_kernel(const st_gemm_desc d) {
+    conv_gemm_split3_body<WM, WN, TM, TN, STAGES, 0, 2>(d, (int)blockIdx.x);
+}
+
 template <int STAGES, int DIAG = 0>
 __global__ __launch_bounds__(512, 4) void conv_gemm_split3_kernel64(const st_gemm_desc d) {
     conv_gemm_split3_body<2, 2, 1, 1, STAGES, DIAG>(d, (int)blockIdx.x);

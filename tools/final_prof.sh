@@ -24,6 +24,13 @@ for l in sys.stdin:
         d = json.loads(l); print('batch $1 streams $2:', round(d['value'], 2), 'pairs/s', round(d['ms_per_step'], 3), 'ms/step; GEMM family frac', round(d['roofline']['frac'], 4))"
 done > gpurun_out/${TAG}_batch_sweep.txt
 cat gpurun_out/${TAG}_batch_sweep.txt
+# the product harness with 2 pairs per forward (the sweep's best point) beside the default bench line's 4
+python bench.py --no-cpu-baseline --no-corr-roofline --harness-batch 2 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_harness_batch2.json
+python -c "
+import json
+for f in ('${TAG}_bench_nocpu', '${TAG}_bench_harness_batch2'):
+    d = json.load(open('gpurun_out/' + f + '.json')); print(f, 'value', round(d['value'], 2), 'harness', round(d['harness_pairs_per_s'], 2), 'batched', round(d['harness_batched_pairs_per_s'], 2))
+" > gpurun_out/${TAG}_harness_batch.txt; cat gpurun_out/${TAG}_harness_batch.txt
 python bench.py --workload 1024 --steps 60 --warmup 8 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${TAG}_bench_1024.json
 rm -rf gpurun_out/prof_final
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o p -- python3 bench.py --no-cpu-baseline --no-corr-roofline --harness none > gpurun_out/prof_final.log 2>&1
@@ -41,6 +48,10 @@ bash tools/run_pmc_shapes.sh $TAG
 bash tools/dma_gemm_pmc.sh > /dev/null 2>&1
 tail -n 3 gpurun_out/r5_dma_gemm_sq_counters.txt
 bash tools/mfma_util.sh > gpurun_out/${TAG}_mfma_utilisation.txt 2>/dev/null
+bash tools/mlp_split3_pmc.sh > /dev/null 2>&1
+python tools/mlp_split3_probe.py --json gpurun_out/${TAG}_mlp_split3_probe.json > gpurun_out/${TAG}_mlp_split3_probe.txt 2>/dev/null
+ST_MLP3_DIAG=1 python tools/mlp_split3_diag.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_mlp_split3_diag.txt
+tools/probes/_bin/mbc > gpurun_out/${TAG}_mfma_bf16_chain.txt 2>/dev/null
 tail -n 3 gpurun_out/${TAG}_mfma_utilisation.txt
 python tools/bench_out_harness.py 48 2>/dev/null | grep '^{' > gpurun_out/${TAG}_out_harness.json; cat gpurun_out/${TAG}_out_harness.json
 python bench.py 2>>gpurun_out/${TAG}_bench.err | grep '^{' > gpurun_out/${TAG}_bench.json
