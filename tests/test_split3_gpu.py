@@ -64,7 +64,11 @@ def conv_ref64(x, w, B, H, W, Cin, kh, kw):
 @pytest.mark.parametrize("B,H,W,Cin,N,kh,kw,tile,split", [
     (2, 16, 16, 128, 128, 1, 5, 0, 0), (2, 16, 16, 128, 128, 5, 1, 34, 1), (1, 24, 40, 64, 126, 3, 3, 34, 1), (1, 24, 40, 64, 126, 3, 3, 32, 1),
     (2, 32, 32, 96, 256, 3, 3, 33, 1), (1, 16, 16, 256, 64, 3, 3, 34, 3), (1, 64, 64, 384, 256, 1, 5, 32, 1), (1, 8, 12, 32, 40, 1, 1, 31, 1),
-    (1, 64, 64, 384, 256, 5, 1, 36, 1), (1, 16, 32, 128, 192, 3, 3, 35, 2)])
+    (1, 64, 64, 384, 256, 5, 1, 36, 1), (1, 16, 32, 128, 192, 3, 3, 35, 2),
+    # two consumer groups per workgroup (K halves of every step, partial tiles summed through LDS): 128x64 and 64x64 tiles; ragged M / N; an odd number of
+    # K steps (the last step has no successor in either fragment buffer); the shape the launcher picks tile 39 for by itself (one 64x64 tile per CU, K >= 1024)
+    (2, 24, 40, 128, 256, 1, 5, 38, 0), (1, 16, 24, 64, 96, 3, 3, 39, 0), (2, 19, 23, 96, 136, 5, 1, 38, 0), (1, 19, 23, 96, 72, 5, 1, 39, 0),
+    (2, 64, 64, 384, 128, 1, 5, 0, 0)])
 def test_split3_conv_vs_fp32_kernel_and_fp64(ops, B, H, W, Cin, N, kh, kw, tile, split):
     x = dev(torch.randn(B * H * W, Cin, generator=g(2)))
     w = dev(torch.randn(N, kh * kw * Cin, generator=g(3)) / (kh * kw * Cin) ** 0.5)
