@@ -529,7 +529,7 @@ def worker(args):
             "value": world * args.steps * nb / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (decoder contractions: exact 3xbf16 split of both operands, 6 products on the bf16 matrix cores, fp32 accumulate -- error vs fp64 "
+            "dtype": ("f32 (decoder contractions, PatchEmbed's third conv and the C = 128 block tails: exact 3xbf16 split of both operands, 6 products on the bf16 matrix cores, fp32 accumulate -- error vs fp64 "
                       "0.83x the fp32 MFMA chain's; everything else fp32)") if split3_on else "f32",
             "value_exact_fp32": value_exact, "data": "synthetic",
             "effective_warmup_steps": nstreams + settle + max(args.warmup, nstreams),
@@ -544,15 +544,15 @@ def worker(args):
             "harness": harness,
             "value_1_in_flight": None if dt1 is None else world * max(10, args.steps // 2) * nb / dt1,
             "per_rank_pairs_per_s": {"min": min(per_rank_pairs_s), "max": max(per_rank_pairs_s), "ranks": len(per_rank_pairs_s)},
-            "roofline": {"bound": "mfma", "kernel": "GEMM family: conv_gemm_split3_kernel (decoder contractions, exact 3xbf16 split on the bf16 matrix cores) + the fp32-MFMA kernels conv_gemm_dma_kernel + rowstream_gemm_kernel + rowmlp128_kernel + rowchain128_kernel + conv_gemm_kernel + skinny / narrow variants + split-K reducers (every st_conv_gemm / st_mlp128 / st_linear_chain128 launch of one step)",
+            "roofline": {"bound": "mfma", "kernel": "GEMM family: conv_gemm_split3_kernel / _kpar_kernel / _pair_kernel / _persist_kernel + rowmlp128_split3_kernel (decoder contractions, PatchEmbed c4, block tails: exact 3xbf16 split on the bf16 matrix cores) + the fp32-MFMA kernels conv_gemm_dma_kernel + rowstream_gemm_kernel + rowmlp128_kernel + rowchain128_kernel + conv_gemm_kernel + skinny / narrow variants + split-K reducers (every st_conv_gemm / st_mlp128 / st_linear_chain128 launch of one step)",
                          "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                          "frac_note": "fp32-EQUIVALENT FLOPs (2 M N K per launch) of the whole family over its kernel time against the fp32-MFMA peak: the split3 launches execute 6 bf16 products per fp32 product on the 16x faster bf16 pipe, so this fraction is not bounded by 1 for them -- `split3` and `fp32_mfma` below price each part against its own pipe",
                          "split3": None if not split3_on else {
-                             "kernel": "conv_gemm_split3_kernel / conv_gemm_split3_kernel64 / conv_gemm_split3_pair_kernel (csrc/gemm_split3.h)",
+                             "kernel": "conv_gemm_split3_kernel / _kernel64 / _kpar_kernel / _pair_kernel / _persist_kernel (csrc/gemm_split3.h), rowmlp128_split3_kernel (csrc/mlp_split3.h)",
                              "launches_per_step": inst["split3_launches"], "kernel_ms_per_step": inst["split3_ms"], "fp32_equivalent_tflops": s3_tf,
                              "bound": "mfma", "achieved": 6.0 * s3_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (bf16 products executed: 6 per fp32 product)",
                              "frac": 6.0 * s3_tf / BF16_MFMA_PEAK_TFLOPS,
-                             "note": "in-kernel: MFMA-bound at the clock the chip holds under this load (1.47 GHz in the K loop with the DMA ring running, 2.2 GHz without: tools/split3_clock.py, profiles/r6_split3_clock.txt), 0.49 of the matrix cycles of a 2.03 GHz dispatch (profiles/r6_split3_sq_counters.txt)"},
+                             "note": "bounded by what feeds the matrix pipe, not by the pipe: two waves of a SIMD issue one v_mfma_f32_32x32x16_bf16 per 16.8 cycles (tools/probes/mfma_bf16_chain.hip), the GEMM loop sits at 29.5 -- a 64x64 tile needs 1 KB of ds_read_b128 (128 B/clk/CU) and 0.5 KB of LDS-DMA (64 B/clk/CU) per MFMA, one consumer wave issues one per 32 cycles -- at 1.47 GHz with the DMA ring running (profiles/r6_split3_clock.txt, r6_split3_sq_counters.txt); the fused block tail at 96 x ~23 + 4 x (VALU instructions) cycles per chunk: each MFMA holds the SIMD's VALU issue (profiles/r6_mlp_split3_diag.txt)"},
                          "fp32_mfma": {"kernel_ms_per_step": f32_ms, "achieved": (flops - inst["split3_flops"]) / f32_ms / 1e9, "peak": FP32_MFMA_PEAK_TFLOPS,
                                        "frac": (flops - inst["split3_flops"]) / f32_ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": launches - inst["split3_launches"]},
                          "traffic": traffic, "traffic_unit": "HBM bytes per step (all launches of the family)", "traffic_source": tsrc,
