@@ -129,7 +129,7 @@ int st_set_gemm_observer(void* callback, void* user);
  *   plan4[0] kernel family (0 skinny_gemm, 1 narrow_conv, 2 conv_gemm_kernel [register-staged], 3 conv_gemm_dma_kernel,
  *            4 rowstream_gemm_kernel, 5 rowchain128_kernel [st_linear_chain128, reported to the observer as M x 128L x 128],
  *            6 rowmlp128_kernel [st_mlp128, reported as M x 2 hidden x 128], 7 patch_c0c2_kernel [st_patch_conv12], 8 conv_gemm_split3_kernel
- *            [st_gemm_desc.split3: tile_cfg 31..37], 9 rowmlp128_split3_kernel [st_mlp128_split3])
+ *            [st_gemm_desc.split3: tile_cfg 31..37], 9 rowmlp128_split3_kernel [st_mlp128_split3], 10 rowlin128_split3_kernel [st_rowlin128_split3])
  *   plan4[1] tile_cfg actually used, plan4[2] split_k actually used, plan4[3] 1 = persistent M walk, 2 / 3 = first / second
  *            member of an st_conv_gemm_pair launch (one dispatch, reported with the second member).
  * Used by tools/gemm_shapes_csv.py to label every launch of a step (profiles/r2_gemm_shapes.csv). */
@@ -207,6 +207,15 @@ int st_mlp128_split3_image_bytes(int32_t hidden, int32_t with_proj, int64_t* byt
 int st_mlp128_split3_pack(const float* w1, const float* b1, const float* w2, const float* wp, const float* bp, int32_t hidden, void* image,
                           int64_t image_bytes, void* stream);
 int st_mlp128_split3(const st_mlp_desc* desc, const void* image, int64_t image_bytes, void* stream);
+/* out[M, N] = LayerNorm(a)[M, 128] . w^T + b on the exact-split contraction (round 6, csrc/mlp_split3.h, rowlin128_split3_kernel): the q | k | v
+ * projections behind norm1 (twins.py:598-600, encoder.py:156-160), i.e. st_conv_gemm with a_ln for K = 128.  ln = 1: layer norm without affine
+ * (gamma / beta folded into w / b by the caller), ln = 0: plain rows.  w [N, 128] row-major, b [N] or NULL, N % 32 == 0; weights packed once:
+ *   st_rowlin128_split3_image_bytes(N, &bytes), st_rowlin128_split3_pack(w, b, N, image, image_bytes, stream).  aux (or NULL): a table
+ * [ceil(M / row_div), ld_aux] whose row (m / row_div) is added to output row m (st_gemm_desc.aux0 with row_div).  plan4[0] = 10.      */
+int st_rowlin128_split3_image_bytes(int32_t N, int64_t* bytes);
+int st_rowlin128_split3_pack(const float* w, const float* b, int32_t N, void* image, int64_t image_bytes, void* stream);
+int st_rowlin128_split3(const float* a, int32_t lda, float* out, int32_t ldo, int32_t M, int32_t N, int32_t ln, float ln_eps, const void* image,
+                        int64_t image_bytes, const float* aux, int32_t ld_aux, int32_t row_div, void* stream);
 
 /* All-pairs correlation volume, MemoryEncoder.corr (encoder.py:359-369):
  *   f1, f2 [B, N, C] channels-last features -> vol [B, N1, N2] = f1 . f2^T (no scaling). */

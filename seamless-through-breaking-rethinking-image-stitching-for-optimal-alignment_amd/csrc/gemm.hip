@@ -1633,6 +1633,49 @@ extern "C" int st_mlp128_split3(const st_mlp_desc* desc, const void* image, int6
     return ST_OK;
 }
 
+// LayerNorm -> Linear(128 -> N) + bias on the exact-split contraction (csrc/mlp_split3.h, rowlin128_split3_kernel): the weights packed once into
+// N / 32 stage images of 25 KiB
+extern "C" int st_rowlin128_split3_image_bytes(int32_t N, int64_t* bytes) {
+    if (!bytes || N < 32 || N > 4096 || (N & 31)) return ST_EINVAL;
+    *bytes = (int64_t)(N / 32) * LS3_STAGE_B;
+    return ST_OK;
+}
+extern "C" int st_rowlin128_split3_pack(const float* w, const float* b, int32_t N, void* image, int64_t image_bytes, void* stream) {
+    if (!w || !image || N < 32 || N > 4096 || (N & 31) || ((uintptr_t)image & 15) || image_bytes < (int64_t)(N / 32) * LS3_STAGE_B) return ST_EINVAL;
+    hipLaunchKernelGGL(rowlin_split3_pack_kernel, dim3(3, N / 32), dim3(256), 0, (hipStream_t)stream, w, b, (unsigned char*)image);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+extern "C" int st_rowlin128_split3(const float* a, int32_t lda, float* out, int32_t ldo, int32_t M, int32_t N, int32_t ln, float ln_eps, const void* image,
+                                   int64_t image_bytes, const float* aux, int32_t ld_aux, int32_t row_div, void* stream) {
+    if (aux && (ld_aux < N || (ld_aux & 3) || row_div < 1 || ((uintptr_t)aux & 15) || aux == out)) return ST_EINVAL;
+    if (!a || !out || !image || M <= 0 || N < 32 || N > 4096 || (N & 31) || lda < 128 || ldo < N || (lda & 3) || (ldo & 3) || a == out) return ST_EINVAL;
+    if ((((uintptr_t)a | (uintptr_t)out | (uintptr_t)image) & 15) || (int64_t)M * (lda > ldo ? lda : ldo) >= ((int64_t)1 << 40)) return ST_EINVAL;
+    const int64_t need = (int64_t)(N / 32) * LS3_STAGE_B;
+    if (image_bytes < need) return ST_EINVAL;
+    const int nblk = (M + 31) / 32;
+    int G = (nblk + 3) / 4;
+    if (G > 512) G = 512;                                       // 75 KB of LDS: two workgroups per CU
+    const size_t lds = (size_t)3 * LS3_STAGE_B;
+    auto kern = aux ? rowlin128_split3_kernel<true> : rowlin128_split3_kernel<false>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    st_gemm_observer_fn obs = g_observer;
+    st_gemm_desc od;
+    if (obs) {
+        memset(&od, 0, sizeof(od));
+        od.a = a; od.c = out; od.w = (const float*)image;
+        od.M = M; od.N = N; od.K = 128; od.H = 1; od.W = M; od.Cin = 128; od.ldx = lda; od.ldc = ldo; od.ldw = 128;
+        od.kh = od.kw = od.sh = od.sw = 1; od.Ho = 1; od.Wo = M; od.batch = 1; od.alpha = 1.f; od.split3 = 1;
+        obs(&od, stream, 0, g_observer_user);
+    }
+    g_last_plan[0] = 10; g_last_plan[1] = 40; g_last_plan[2] = 1; g_last_plan[3] = 1;
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, (hipStream_t)stream, a, (int)lda, out, (int)ldo, (int)M, (int)N, (int)ln, ln_eps,
+                       (const unsigned char*)image, (unsigned)need, aux, (int)ld_aux, (int)(row_div > 0 ? row_div : 1));
+    if (obs) obs(&od, stream, 1, g_observer_user);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 // split-K tail: sum the K-slice slabs [split][M][N] in slice order (deterministic) + epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const st_gemm_desc d) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -413,6 +413,167 @@ __global__ __launch_bounds__(256, 1) void rowmlp128_split3_kernel(const st_mlp_d
     if (DIAG && tid == 0)
         for (int i = 0; i < 8; ++i) diag[8 * blockIdx.x + i] = tsum[i];
 }
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm -> Linear(128 -> N) + bias over 128-wide rows (the q | k | v projections behind norm1: twins.py:598-600, encoder.py:156-160; the operator of
+// rowstream_gemm_kernel with a_ln) on the same machinery: a wave's 32-row block as three bf16 planes in registers, the weights' 32-feature chunks as
+// pre-split LDS images ([W chunk 3 x 32 x 256 B | 32 bias floats] = 25 KiB per step) through a 3-stage DMA ring, 48 MFMAs per chunk, the chunk's 32
+// output features stored straight from the accumulator layout (16-byte runs).  75 KB of LDS and ~150 registers: two workgroups per CU, so one wave's
+// stores and LayerNorm meet the other's MFMAs.
+#define LS3_STAGE_B (MS3_W1_B + MS3_BIAS_B)
+
+// grid (3, N / 32) x 256 threads: blocks 0-1 the 512 slots of the chunk, 2 the bias floats
+__global__ __launch_bounds__(256) void rowlin_split3_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, unsigned char* __restrict__ image) {
+    const int c = blockIdx.y, t = threadIdx.x;
+    unsigned char* st = image + (size_t)c * LS3_STAGE_B;
+    if (blockIdx.x < 2) {
+        const int idx = blockIdx.x * 256 + t, r = idx >> 4, sl = idx & 15, ks = sl >> 1, lh = sl & 1;
+        const float* W = w + (size_t)(32 * c + r) * 128;
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 a0, a1, a2;
+            st_split3(W[16 * ks + 8 * (e >> 2) + 4 * lh + (e & 3)], a0, a1, a2);
+            h[e] = a0; m[e] = a1; l[e] = a2;
+        }
+        unsigned char* o = st + r * 256 + ((sl ^ (r & 15)) << 4);
+        *reinterpret_cast<bf16x8*>(o) = h;
+        *reinterpret_cast<bf16x8*>(o + 8192) = m;
+        *reinterpret_cast<bf16x8*>(o + 16384) = l;
+    } else {
+        reinterpret_cast<float*>(st + MS3_W1_B)[t] = (t < 32 && b) ? b[32 * c + t] : 0.f;
+    }
+}
+
+// AUX: + aux[row / row_div, col] (a per-position table shared by row_div consecutive rows: the context / position part of q | k, encoder.py:95-110)
+template <bool AUX>
+__global__ __launch_bounds__(256, 2) void rowlin128_split3_kernel(const float* __restrict__ a, const int lda, float* __restrict__ out, const int ldo, const int M,
+                                                                  const int N, const int ln, const float ln_eps, const unsigned char* __restrict__ image,
+                                                                  const unsigned image_bytes, const float* __restrict__ aux, const int ld_aux, const int row_div) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int nblk = (M + 31) >> 5;
+    const int G = (int)gridDim.x;
+    const int blk0 = (int)blockIdx.x * 4;
+    const int rounds = blk0 < nblk ? (nblk - blk0 + G * 4 - 1) / (G * 4) : 0;
+    const int spr = N >> 5, total = rounds * spr;
+    if (total == 0) return;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)sm3;
+    const i32x4 rsd = make_rsrc(image, image_bytes);
+    const unsigned vlin = (unsigned)lane << 4;
+    int s_dma = 0, g_dma = 0, q_dma = 0;
+    auto dma_step = [&]() {                                      // wave w: bytes [6 144 w, 6 144 (w + 1)) of the chunk as a run of four + a run of two; wave 0 the bias KiB
+        const unsigned dst = lds0 + (unsigned)(g_dma * LS3_STAGE_B), src = (unsigned)(s_dma * LS3_STAGE_B), o = (unsigned)wave * 6144u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds"
+                     : : "s"(dst + o), "v"(vlin), "s"(rsd), "s"(src + o) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds"
+                     : : "s"(dst + o + 4096u), "v"(vlin), "s"(rsd), "s"(src + o + 4096u) : "memory");
+        if (wave == 0) lds_dma16(rsd, dst + (unsigned)MS3_W1_B, vlin, src + (unsigned)MS3_W1_B);
+        ++q_dma;
+        s_dma = s_dma + 1 == spr ? 0 : s_dma + 1;
+        g_dma = g_dma + 1 == 3 ? 0 : g_dma + 1;
+    };
+    dma_step();
+    if (total > 1) dma_step();
+    int fo1[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) fo1[ks] = li * 256 + (((2 * ks + lh) ^ (li & 15)) << 4);
+    int g = 0;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int blk = blk0 + wave + rd * G * 4;
+        const bool active = blk < nblk;                         // wave-uniform; an idle wave still copies weights and meets the barriers
+        const int row = blk * 32 + li;
+        const bool rok = active && row < M;
+        const size_t rowc = (size_t)(active && row < M ? row : M - 1);
+        u32x4 xp[3][8];
+        if (active) {
+            float4 x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = *reinterpret_cast<const float4*>(a + rowc * lda + 8 * j + 4 * lh);
+            if (ln) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+                s += __shfl_xor(s, 32, 64);
+                const float mean = s * (1.0f / 128.0f);
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
+                    v += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+                }
+                v += __shfl_xor(v, 32, 64);
+                const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + ln_eps);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { x[j].x *= rstd; x[j].y *= rstd; x[j].z *= rstd; x[j].w *= rstd; }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                ms3_split_pair(x[j].x, x[j].y, h0, m0, l0);
+                ms3_split_pair(x[j].z, x[j].w, h1, m1, l1);
+                xp[0][j >> 1][2 * (j & 1)] = h0; xp[0][j >> 1][2 * (j & 1) + 1] = h1;
+                xp[1][j >> 1][2 * (j & 1)] = m0; xp[1][j >> 1][2 * (j & 1) + 1] = m1;
+                xp[2][j >> 1][2 * (j & 1)] = l0; xp[2][j >> 1][2 * (j & 1) + 1] = l1;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int c = 0; c < spr; ++c) {
+            // this wave's DMA pieces of the step have landed; the four stores of its previous chunk (younger than those pieces; an active wave always
+            // stores: its first row exists) may still be in flight
+            if (c > 0 && active) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (q_dma < total) dma_step();
+            if (active) {
+                const unsigned char* ws_ = sm3 + g * LS3_STAGE_B;
+                float4 ev[4];
+                if (AUX) {                                      // the chunk's table values: requested before the MFMAs, used after them
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) ev[jj] = *reinterpret_cast<const float4*>(aux + (rowc / (size_t)row_div) * ld_aux + (c << 5) + 8 * jj + 4 * lh);
+                }
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                u32x4 f[3], fn[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(ws_ + p * 8192 + fo1[0]);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int kn = ks + 1 < 8 ? ks + 1 : ks;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) fn[p] = *reinterpret_cast<const u32x4*>(ws_ + p * 8192 + fo1[kn]);
+                    MS3_SIX(acc, f, xp[0][ks], xp[1][ks], xp[2][ks])
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) f[p] = fn[p];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float* bs = reinterpret_cast<const float*>(ws_ + MS3_W1_B);
+                float4 v[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bs + 8 * jj + 4 * lh);
+                    v[jj] = make_float4(acc[4 * jj] + bv.x, acc[4 * jj + 1] + bv.y, acc[4 * jj + 2] + bv.z, acc[4 * jj + 3] + bv.w);     // (acc + bias) + table: the fp32 epilogue's order
+                    if (AUX) { v[jj].x += ev[jj].x; v[jj].y += ev[jj].y; v[jj].z += ev[jj].z; v[jj].w += ev[jj].w; }
+                }
+                if (rok) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<float4*>(out + rowc * ldo + (c << 5) + 8 * jj + 4 * lh) = v[jj];
+                }
+            }
+            g = g + 1 == 3 ? 0 : g + 1;
+        }
+    }
+}
+
 #undef MS3_T0
 #undef MS3_T1
 #undef MS3_PHASE2

@@ -50,6 +50,8 @@ assert not (SPLIT3 and FORK_ENC), "ST_FORK_ENC is an fp32-path experiment"
 S3_PAIR = os.environ.get("ST_S3_PAIR", "1") != "0"
 S3_PE = os.environ.get("ST_S3_PE", "1") != "0"                 # PatchEmbed's third convolution on planes
 S3_MLP = os.environ.get("ST_S3_MLP", "1") != "0"               # the C = 128 block tails (st_mlp128) on the split3 kernel (st_mlp128_split3, weights packed into its image once)
+S3_LIN = os.environ.get("ST_S3_LIN", "1") != "0"               # LayerNorm -> q | k | v projection (K = 128, N = 384) on the split3 row kernel (st_rowlin128_split3)
+S3_CHAIN = os.environ.get("ST_S3_CHAIN", "1") != "0"           # the latent layers' 128-wide tails (st_linear_chain128) on the same split3 kernel, hidden = 128
 S3_AGG = os.environ.get("ST_S3_AGG", "0") == "1"               # GMA aggregate on planes (measured equal to the fp32 kernel in the chain: HBM-bound; default off)
 S3_OFF = int(os.environ.get("ST_S3_OFF", "0"))     # bisecting aid: bit 1 mask-head conv, 2 flow-head conv, 8 GRU, 16 motion conv, 32 conv pair back on the fp32 kernels
 _SIDE = {}
@@ -102,9 +104,17 @@ class FlowFormer(ParamTree):
 
         def mlp_image(fc1_ln, fc2, proj):
             """the split3 image of a block tail (projection + LayerNorm-folded fc1 + fc2), or None: CPU weights (tests of the pack layouts), switch off"""
-            if not (SPLIT3 and S3_MLP and FUSE_LN and FUSE_MLP and FUSE_PROJ and fc1_ln[0].is_cuda and fc1_ln[0].shape[1] == 128 and proj[0].shape == (128, 128)):
+            if not (SPLIT3 and S3_MLP and FUSE_LN and FUSE_MLP and FUSE_PROJ and fc1_ln[0].is_cuda and fc1_ln[0].shape[1] == 128
+                    and (proj is None or proj[0].shape == (128, 128))):
                 return None
-            return ops.mlp128_split3_pack(fc1_ln[0], fc1_ln[1], fc2[0], proj=(proj[0], proj[1]))
+            return ops.mlp128_split3_pack(fc1_ln[0], fc1_ln[1], fc2[0], proj=None if proj is None else (proj[0], proj[1]))
+
+        def lin_image(w_b):
+            """the split3 image of a LayerNorm-folded Linear(128 -> N), or None (CPU weights, switch off)"""
+            w, b = w_b if isinstance(w_b, (tuple, list)) else (w_b, None)
+            if not (SPLIT3 and S3_LIN and FUSE_LN and w.is_cuda and w.shape[1] == 128 and w.shape[0] % 32 == 0 and w.is_contiguous()):
+                return None
+            return ops.rowlin128_split3_pack(w, b)
 
         def twins(prefix):
             t = {}
@@ -121,6 +131,7 @@ class FlowFormer(ParamTree):
                                   pads=tuple(qkv_b[i * C:(i + 1) * C].expand(49, C).contiguous() for i in range(3)))
                 if C == 128:
                     t[f"l{s}"]["qkv_ln"] = ops.fold_layernorm(*t[f"l{s}"]["n1"], qkv_w, qkv_b)
+                    t[f"l{s}"]["qkv_s3"] = lin_image(t[f"l{s}"]["qkv_ln"])
                     t[f"l{s}"]["fc1_ln"] = ops.fold_layernorm(*t[f"l{s}"]["n2"], *t[f"l{s}"]["fc1"])
                     t[f"l{s}"]["mlp_s3"] = mlp_image(t[f"l{s}"]["fc1_ln"], t[f"l{s}"]["fc2"], t[f"l{s}"]["proj"])
                 w9 = p[prefix + f"pos_block.{s}.proj.0.weight"].reshape(C, 9).t().contiguous()
@@ -153,8 +164,13 @@ class FlowFormer(ParamTree):
             if fuse_qkv:
                 d["qkv"] = cat_lin([name + ".q", name + ".k", name + ".v"])
                 d["qkv_ln"] = ops.fold_layernorm(*d["n1"], *d["qkv"])
+                d["qkv_s3"] = lin_image(d["qkv_ln"])
             d["kv"] = cat_lin([name + ".k", name + ".v"])
             d["f0_ln"] = ops.fold_layernorm(*d["n2"], *d["f0"])
+            if S3_CHAIN:
+                # the latent layers' tails are the same operator as the Block tails with hidden = 128 (proj + residual -> LN -> ffn.0 + GELU -> ffn.3 + residual)
+                d["mlp_s3"] = mlp_image(d["f0_ln"], d["f3"], d["proj"])
+                d["mlp_s3_plain"] = mlp_image(d["f0_ln"], d["f3"], None)
             return d
         pk["xin"] = attn_layer(c + "input_layer", False)
         # first layer: the queries are the (normalised, projected) latent tokens themselves -- constants of the weights.
@@ -199,6 +215,7 @@ class FlowFormer(ParamTree):
             Vd["ltab"] = (torch.cat([Vd["lq"][0], Vd["lk"][0], z128], 0).contiguous(), torch.cat([Vd["lq"][1], Vd["lk"][1], Vd["lv"][1]]).contiguous())
             Vd["gtab"] = (torch.cat([Vd["gskc"], torch.zeros_like(Vd["gskc"])], 0).contiguous(), torch.cat([Vd["gskb"], Vd["gsv"][1]]).contiguous())
             vert[-1]["lqkv_ln"] = ops.fold_layernorm(*vert[-1]["ln1"], vert[-1]["lqkv"])
+            vert[-1]["lqkv_s3"] = lin_image(vert[-1]["lqkv_ln"])
             vert[-1]["lfc1_ln"] = ops.fold_layernorm(*vert[-1]["ln2"], *vert[-1]["lfc1"])
             vert[-1]["gfc1_ln"] = ops.fold_layernorm(*vert[-1]["gn2"], *vert[-1]["gfc1"])
             vert[-1]["lmlp_s3"] = mlp_image(vert[-1]["lfc1_ln"], vert[-1]["lfc2"], vert[-1]["lproj"])
@@ -303,7 +320,9 @@ class FlowFormer(ParamTree):
             L = t[f"l{s}"]
             y = _new(N, C, dev)
             qkv = _new(N, 3 * C, dev)
-            if "qkv_ln" in L and FUSE_LN:
+            if L.get("qkv_s3") is not None and FUSE_LN:
+                ops.rowlin128_split3(x, qkv, L["qkv_s3"], ln_eps=1e-6)
+            elif "qkv_ln" in L and FUSE_LN:
                 ops.conv_gemm(x, L["qkv_ln"][0], qkv, bias=L["qkv_ln"][1], ln_eps=1e-6)
             else:
                 ops.layernorm(x, L["n1"][0], L["n1"][1], y, 1e-6)
@@ -397,7 +416,9 @@ class FlowFormer(ParamTree):
             ops.conv_gemm(att, L["proj"][0], x1, bias=proj_b, aux0=lat, row_mod=nl)
         else:
             qkv = _new(M * nl, 384, dev)
-            if FUSE_LN:
+            if FUSE_LN and L.get("qkv_s3") is not None:
+                ops.rowlin128_split3(x, qkv, L["qkv_s3"], ln_eps=1e-5)
+            elif FUSE_LN:
                 ops.conv_gemm(x, L["qkv_ln"][0], qkv, bias=L["qkv_ln"][1], ln_eps=1e-5)
             else:
                 y = _new(M * nl, 128, dev)
@@ -410,6 +431,8 @@ class FlowFormer(ParamTree):
                 # proj + residual -> LayerNorm -> ffn.0 + GELU -> ffn.3 + residual in ONE launch: x1 and the hidden activation
                 # never leave the CU (encoder.py:163-172)
                 o = _new(M * nl, 128, dev)
+                if L.get("mlp_s3") is not None:                 # ... on the split3 kernel (st_mlp128_split3, hidden = 128)
+                    return ops.mlp128(att, o, L["f0_ln"][0], L["f0_ln"][1], L["f3"][0], L["f3"][1], ln_eps=1e-5, proj=(L["proj"][0], L["proj"][1], x), image=L["mlp_s3"])
                 return ops.linear_chain128(att, o, [dict(w=L["proj"][0], bias=L["proj"][1], res=x),
                                                     dict(w=L["f0_ln"][0], bias=L["f0_ln"][1], act="gelu", ln_eps=1e-5),
                                                     dict(w=L["f3"][0], bias=L["f3"][1], res=1)])
@@ -421,6 +444,8 @@ class FlowFormer(ParamTree):
     def _mlp_plain(x, L):
         dev = x.device
         if FUSE_CHAIN:                                          # LayerNorm -> ffn.0 + GELU -> ffn.3 + residual, one launch
+            if L.get("mlp_s3_plain") is not None:
+                return ops.mlp128(x, _new(x.shape[0], x.shape[1], dev), L["f0_ln"][0], L["f0_ln"][1], L["f3"][0], L["f3"][1], ln_eps=1e-5, image=L["mlp_s3_plain"])
             return ops.linear_chain128(x, _new(x.shape[0], x.shape[1], dev),
                                        [dict(w=L["f0_ln"][0], bias=L["f0_ln"][1], act="gelu", ln_eps=1e-5), dict(w=L["f3"][0], bias=L["f3"][1], res=0)])
         h = _new(x.shape[0], L["f0"][0].shape[0], dev)
@@ -454,7 +479,9 @@ class FlowFormer(ParamTree):
         T = _new(B * N, 3 * C, dev)
         ops.conv_gemm(z, V["ltab"][0], T, bias=V["ltab"][1])
         qkv = _new(R, 3 * C, dev)
-        if FUSE_LN:
+        if FUSE_LN and V.get("lqkv_s3") is not None:
+            ops.rowlin128_split3(x, qkv, V["lqkv_s3"], ln_eps=1e-5, aux=T, row_div=nl)
+        elif FUSE_LN:
             ops.conv_gemm(x, V["lqkv_ln"][0], qkv, bias=V["lqkv_ln"][1], aux0=T, row_div=nl, ln_eps=1e-5)
         else:
             ops.conv_gemm(y, V["lqkv"], qkv, aux0=T, row_div=nl)

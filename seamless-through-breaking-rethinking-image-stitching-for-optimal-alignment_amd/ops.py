@@ -271,6 +271,28 @@ def linear_chain128(a, out, layers):
     return out
 
 
+def rowlin128_split3_pack(w, b):
+    """weights of a Linear(128 -> N) -> the image st_rowlin128_split3 streams (uint8 tensor; pack once per weight load)"""
+    N = w.shape[0]
+    assert w.shape == (N, 128) and w.is_contiguous() and (b is None or b.shape == (N,))
+    nb = C.c_int64(0)
+    check(lib.st_rowlin128_split3_image_bytes(N, C.byref(nb)), "st_rowlin128_split3_image_bytes")
+    img = torch.empty(nb.value, dtype=torch.uint8, device=w.device)
+    check(lib.st_rowlin128_split3_pack(_p(w), _p(b), N, C.c_void_p(img.data_ptr()), nb.value, _stream()), "st_rowlin128_split3_pack")
+    return img
+
+
+def rowlin128_split3(a, out, image, ln_eps=None, aux=None, row_div=1):
+    """out = LayerNorm(a) @ w^T + b [+ aux[row // row_div]] (ln_eps None: no LayerNorm) over 128-wide rows with the weights of `image` (rowlin128_split3_pack)"""
+    assert a.shape[1] == 128 and out.shape[0] == a.shape[0] and out.shape[1] % 32 == 0
+    if aux is not None:
+        assert aux.shape[1] == out.shape[1] and aux.shape[0] * row_div >= a.shape[0]
+    check(lib.st_rowlin128_split3(_p(a), _ld(a), _p(out), _ld(out), a.shape[0], out.shape[1], 1 if ln_eps is not None else 0,
+                                  float(ln_eps or 0.0), C.c_void_p(image.data_ptr()), image.numel(), _p(aux), _ld(aux) if aux is not None else 0, row_div,
+                                  _stream()), "st_rowlin128_split3")
+    return out
+
+
 def mlp128_split3_pack(w1, b1, w2, proj=None):
     """weights of one st_mlp128 -> the image st_mlp128_split3 streams (uint8 tensor; pack once per weight load).  proj = (wp, bp or None)."""
     hidden = w1.shape[0]

@@ -377,3 +377,47 @@ def test_mlp128_split3(ops, M, hidden):
             ops.mlp128(xc, xc, dev(w1), dev(b1), dev(w2), dev(b2), image=img)                                  # in place: rejected
         with pytest.raises(ops.StitchErrorBase):
             ops.mlp128(dev(att), torch.empty(M, 128, device="cuda"), dev(w1), dev(b1), dev(w2), dev(b2), image=img, proj=(dev(wp), None, None))   # image packed without the projection: too short
+
+
+@pytest.mark.parametrize("M,N,ln", [(4099, 384, True), (96, 128, False), (17, 32, True), (40001, 384, True), (2048, 256, False)])
+def test_rowlin128_split3(ops, M, N, ln):
+    """st_rowlin128_split3: LayerNorm -> Linear(128 -> N) + bias (the q | k | v projections behind norm1, twins.py:598-600, encoder.py:156-160) with the
+    product as six bf16 MFMA products of planes split in registers: against fp64 the error is bounded by 1.25x that of st_conv_gemm(a_ln) on the same
+    inputs; ragged M (a wave walks several blocks at 40 001 rows), column slices of wider buffers on both sides, no bias."""
+    gg = g(21)
+    x = torch.randn(M, 128, generator=gg) * 1.5 + 0.3
+    w, b = torch.randn(N, 128, generator=gg) / 128 ** 0.5, torch.randn(N, generator=gg) * 0.1
+    gam, bet = torch.rand(128, generator=gg) + 0.5, torch.randn(128, generator=gg) * 0.1
+    xd = x.double()
+    if ln:
+        ref = F.linear(F.layer_norm(xd, (128,), gam.double(), bet.double(), 1e-5), w.double(), b.double())
+        wf, bf = ops.fold_layernorm(dev(gam), dev(bet), dev(w), dev(b))
+    else:
+        ref = F.linear(xd, w.double(), b.double())
+        wf, bf = dev(w), dev(b)
+    xw = torch.zeros(M, 136, device="cuda")
+    xw[:, 4:132] = x.cuda()
+    oe, os_ = torch.empty(M, N, device="cuda"), torch.full((M, N + 8), 7.0, device="cuda")
+    ops.conv_gemm(xw[:, 4:132], wf, oe, bias=bf, ln_eps=1e-5 if ln else None)
+    img = ops.rowlin128_split3_pack(wf, bf)
+    ops.rowlin128_split3(xw[:, 4:132], os_[:, 4:4 + N], img, ln_eps=1e-5 if ln else None)
+    assert (os_[:, :4] == 7.0).all() and (os_[:, 4 + N:] == 7.0).all()
+    scale = ref.pow(2).mean().sqrt().item()
+    ee, es = (oe.cpu().double() - ref), (os_[:, 4:4 + N].cpu().double() - ref)
+    check(f"rowlin128_split3_rms_vs_fp64_{M}_{N}", es.pow(2).mean().sqrt().item() / scale, 1.25 * ee.pow(2).mean().sqrt().item() / scale)
+    check(f"rowlin128_split3_max_vs_fp64_{M}_{N}", es.abs().max().item() / scale, max(2.0 * ee.abs().max().item() / scale, 3e-7))
+    if M == 4099:
+        # + a per-position table shared by 8 consecutive rows (the context / position part of q | k in the vertical layers): against the fp32 kernel's aux0 / row_div
+        T = torch.randn((M + 7) // 8, N, generator=gg)
+        o3, o3e = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        ops.rowlin128_split3(dev(x), o3, img, ln_eps=1e-5 if ln else None, aux=dev(T), row_div=8)
+        ops.conv_gemm(dev(x), wf, o3e, bias=bf, aux0=dev(T), row_div=8, ln_eps=1e-5 if ln else None)
+        ref3 = ref + T.double().repeat_interleave(8, 0)[:M]
+        e3, e3e = (o3.cpu().double() - ref3).pow(2).mean().sqrt().item(), (o3e.cpu().double() - ref3).pow(2).mean().sqrt().item()
+        check(f"rowlin128_split3_aux_rms_vs_fp64_{M}_{N}", e3 / scale, 1.25 * e3e / scale)
+    if M == 96:
+        o2 = torch.empty(M, N, device="cuda")
+        ops.rowlin128_split3(dev(x), o2, ops.rowlin128_split3_pack(dev(w), None))                     # no bias, no LayerNorm
+        assert ((o2.cpu().double() - F.linear(xd, w.double())).abs().max() / scale).item() < 3e-6      # (measured 1.2e-6: a maximum over 12 288 values against the rms scale)
+        with pytest.raises(ops.StitchErrorBase):
+            ops.rowlin128_split3(dev(x), torch.empty(M, N + 32, device="cuda"), img)                    # image packed for fewer output features

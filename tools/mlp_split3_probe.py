@@ -65,6 +65,19 @@ def main():
         out.append(rec)
         print(f"M {M:6d} proj {int(proj)}: exact {te:7.1f} us ({rec['exact_tflops']:6.1f} TF)  split3 {ts:7.1f} us ({rec['split3_tflops_fp32_equiv']:6.1f} TF fp32-equiv, "
               f"{rec['split3_bf16_tflops']:6.1f} TF bf16)  x{te / ts:4.2f}   rms vs fp64: exact {ee:.3e} split3 {es:.3e} (ratio {es / ee:4.2f})  non-finite {rec['nonfinite']}", flush=True)
+    # LayerNorm -> Linear(128 -> N): st_conv_gemm(a_ln) (rowstream_gemm_kernel) against st_rowlin128_split3
+    for M, N in ((65536, 384), (32768, 384), (65536, 128)):
+        x = torch.randn(M, 128, generator=gen).cuda()
+        w, b = (torch.randn(N, 128, generator=gen) / 128 ** 0.5).cuda(), (torch.randn(N, generator=gen) * 0.1).cuda()
+        img = ops.rowlin128_split3_pack(w, b)
+        oe, os_ = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        te = timed(lambda: ops.conv_gemm(x, w, oe, bias=b, ln_eps=1e-5), a.iters)
+        ts = timed(lambda: ops.rowlin128_split3(x, os_, img, ln_eps=1e-5), a.iters)
+        ref = F.linear(F.layer_norm(x.double(), (128,), None, None, 1e-5), w.double(), b.double())
+        sc = ref.pow(2).mean().sqrt().item()
+        ee, es = (oe.double() - ref).pow(2).mean().sqrt().item() / sc, (os_.double() - ref).pow(2).mean().sqrt().item() / sc
+        out.append(dict(op="ln_linear", M=M, N=N, exact_us=te, split3_us=ts, speedup=te / ts, exact_rms_vs_fp64=ee, split3_rms_vs_fp64=es))
+        print(f"LN + Linear M {M:6d} N {N:3d}: exact {te:7.1f} us  split3 {ts:7.1f} us  x{te / ts:4.2f}   rms vs fp64: exact {ee:.3e} split3 {es:.3e} (ratio {es / ee:4.2f})", flush=True)
     if a.json:
         json.dump(out, open(a.json, "w"), indent=1)
 
