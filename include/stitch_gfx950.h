@@ -129,7 +129,7 @@ int st_set_gemm_observer(void* callback, void* user);
  *   plan4[0] kernel family (0 skinny_gemm, 1 narrow_conv, 2 conv_gemm_kernel [register-staged], 3 conv_gemm_dma_kernel,
  *            4 rowstream_gemm_kernel, 5 rowchain128_kernel [st_linear_chain128, reported to the observer as M x 128L x 128],
  *            6 rowmlp128_kernel [st_mlp128, reported as M x 2 hidden x 128], 7 patch_c0c2_kernel [st_patch_conv12], 8 conv_gemm_split3_kernel
- *            [st_gemm_desc.split3: tile_cfg 31..37], 9 rowmlp128_split3_kernel [st_mlp128_split3], 10 rowlin128_split3_kernel [st_rowlin128_split3])
+ *            [st_gemm_desc.split3: tile_cfg 31..37], 9 rowmlp128_split3_kernel [st_mlp128_split3], 10 rowlin128_split3_kernel [st_rowlin128_split3], 11 pe_tail_split3_kernel [st_pe_tail_split3])
  *   plan4[1] tile_cfg actually used, plan4[2] split_k actually used, plan4[3] 1 = persistent M walk, 2 / 3 = first / second
  *            member of an st_conv_gemm_pair launch (one dispatch, reported with the second member).
  * Used by tools/gemm_shapes_csv.py to label every launch of a step (profiles/r2_gemm_shapes.csv). */
@@ -406,7 +406,16 @@ int st_patch_embed(const float* cost_maps, const float* const* weights, int32_t 
  * M <= 16 384 maps per call (2 GiB buffer offsets).  encoder.py:60-95.                                                              */
 int st_patch_embed_split3(const float* cost_maps, const float* const* weights, int32_t ld_f0, const float* pe_bias, void* s2_planes,
                           int64_t s2_pstride, const void* c4_w_planes, int64_t c4_w_pstride, float* s3, float* s4, float* tokens, int32_t M,
-                          int32_t H, int32_t W, void* workspace, int64_t workspace_floats, void* stream);
+                          int32_t H, int32_t W, const void* tail_image, int64_t tail_image_bytes, void* workspace, int64_t workspace_floats, void* stream);
+/* PatchEmbed's tail (encoder.py:77-95) as one launch on the exact-split contraction (csrc/mlp_split3.h, pe_tail_split3_kernel):
+ *   out[R, 128] = LayerNorm_affine( ReLU( x[R, 64] . w1^T + tab[r mod P] ) . w2^T + b2 )
+ * w1 = ffn_with_coord.0's first 64 input columns [128, ld1], tab [P, 128] = its position half + bias (st_patch_embed's pe_bias), w2 [128, 128];
+ * both weight matrices are packed once into a 144-KiB image that the kernel holds in LDS (st_pe_tail_split3_image_bytes / _pack).  st_patch_embed_split3
+ * takes the image as tail_image (NULL = the three separate launches, s4 [M P, 128] scratch required).  plan4[0] = 11, reported as R x 192 x 128.        */
+int st_pe_tail_split3_image_bytes(int64_t* bytes);
+int st_pe_tail_split3_pack(const float* w1, int32_t ld1, const float* w2, void* image, int64_t image_bytes, void* stream);
+int st_pe_tail_split3(const float* x, const float* tab, int32_t P, const void* image, int64_t image_bytes, const float* b2, const float* gamma,
+                      const float* beta, float eps, float* out, int32_t R, void* stream);
 /* GMA Attention.forward (gma.py:54-76), 1 head x 128: attn [B,N,N] = softmax(128^-0.5 q k^T),
  * [q|k] = inp . w_qk^T (w_qk [256,128]); qk scratch [B*N,256].                                        */
 int st_gma_attention(const float* inp, int32_t ld_inp, const float* w_qk, float* qk, float* attn, int32_t B,

@@ -1676,6 +1676,43 @@ extern "C" int st_rowlin128_split3(const float* a, int32_t lda, float* out, int3
     return ST_OK;
 }
 
+// PatchEmbed's tail (csrc/mlp_split3.h, pe_tail_split3_kernel): tokens[R, 128] = LayerNorm(ReLU(x[R, 64] . w1^T + tab[r % P]) . w2^T + b2) in one launch
+extern "C" int st_pe_tail_split3_image_bytes(int64_t* bytes) {
+    if (!bytes) return ST_EINVAL;
+    *bytes = PT3_IMAGE_B;
+    return ST_OK;
+}
+extern "C" int st_pe_tail_split3_pack(const float* w1, int32_t ld1, const float* w2, void* image, int64_t image_bytes, void* stream) {
+    if (!w1 || !w2 || !image || ld1 < 64 || ((uintptr_t)image & 15) || image_bytes < PT3_IMAGE_B) return ST_EINVAL;
+    hipLaunchKernelGGL(pe_tail_split3_pack_kernel, dim3(3, 4), dim3(256), 0, (hipStream_t)stream, w1, (int)ld1, w2, (unsigned char*)image);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+extern "C" int st_pe_tail_split3(const float* x, const float* tab, int32_t P, const void* image, int64_t image_bytes, const float* b2, const float* gamma,
+                                 const float* beta, float eps, float* out, int32_t R, void* stream) {
+    if (!x || !tab || !image || !b2 || !gamma || !beta || !out || R <= 0 || P <= 0 || image_bytes < PT3_IMAGE_B || x == out) return ST_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)tab | (uintptr_t)image | (uintptr_t)out) & 15) || (int64_t)R * 128 >= ((int64_t)1 << 40)) return ST_EINVAL;
+    const int nblk = (R + 31) / 32;
+    int G = (nblk + 3) / 4;
+    if (G > 256) G = 256;                                       // 146 KB of LDS: one workgroup per CU
+    const size_t lds = (size_t)PT3_IMAGE_B + PT3_VEC_B;
+    (void)hipFuncSetAttribute((const void*)pe_tail_split3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    st_gemm_observer_fn obs = g_observer;
+    st_gemm_desc od;
+    if (obs) {                                                  // reported as R x 192 x 128: its FLOPs (2 R (128 . 64 + 128 . 128))
+        memset(&od, 0, sizeof(od));
+        od.a = x; od.c = out; od.w = (const float*)image;
+        od.M = R; od.N = 192; od.K = 128; od.H = 1; od.W = R; od.Cin = 128; od.ldx = 64; od.ldc = 128; od.ldw = 128;
+        od.kh = od.kw = od.sh = od.sw = 1; od.Ho = 1; od.Wo = R; od.batch = 1; od.alpha = 1.f; od.split3 = 1;
+        obs(&od, stream, 0, g_observer_user);
+    }
+    g_last_plan[0] = 11; g_last_plan[1] = 41; g_last_plan[2] = 1; g_last_plan[3] = 1;
+    hipLaunchKernelGGL(pe_tail_split3_kernel, dim3(G), dim3(256), lds, (hipStream_t)stream, x, tab, (const unsigned char*)image, b2, gamma, beta, eps, out, (int)R, (int)P);
+    if (obs) obs(&od, stream, 1, g_observer_user);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 // split-K tail: sum the K-slice slabs [split][M][N] in slice order (deterministic) + epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const st_gemm_desc d) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -574,6 +574,220 @@ __global__ __launch_bounds__(256, 2) void rowlin128_split3_kernel(const float* _
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// PatchEmbed's tail (encoder.py:77-95): tokens = LayerNorm( ffn_with_coord.2( ReLU( ffn_with_coord.0([x | pe(pos)]) ) ) ) over the M * P rows of the 64-channel
+// patch features -- three HBM-bound launches over 524 288 rows per pair (64 -> 128 with the position table, 128 -> 128, LayerNorm: 0.36 ms, the
+// [M P, 128] intermediate written and read twice) as ONE: both weight matrices fit the LDS as pre-split images (4 x 12 KiB + 4 x 24 KiB = 144 KB), so
+// there is no ring and NO barrier after the load: a wave walks its 32-row blocks alone -- rows split into planes in registers, fc1 in four 32-feature
+// chunks (K = 64: 24 MFMAs each, the next chunk's under the table add + ReLU + split of the current one), fc2 on four accumulator tiles (48 MFMAs per
+// chunk), bias + LayerNorm (affine) in registers, the next block's rows and table values requested one block ahead.
+#define PT3_W1_B 12288            // 3 planes x 32 rows x 128 B (K = 64)
+#define PT3_IMAGE_B (4 * PT3_W1_B + 4 * MS3_W2_B)
+#define PT3_VEC_B 1536            // b2 | gamma | beta
+
+// grid (3, 4) x 256 threads: block 0 the 256 slots of W1 chunk c (slot = 16-k step and lane half of a row, XOR (row >> 1) & 7), 1-2 the 512 slots of W2 slice c
+__global__ __launch_bounds__(256) void pe_tail_split3_pack_kernel(const float* __restrict__ w1, const int ld1, const float* __restrict__ w2, unsigned char* __restrict__ image) {
+    const int c = blockIdx.y, t = threadIdx.x;
+    bf16x8 h, m, l;
+    unsigned char* o;
+    if (blockIdx.x == 0) {
+        const int r = t >> 3, sl = t & 7, ks = sl >> 1, lh = sl & 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 a0, a1, a2;
+            st_split3(w1[(size_t)(32 * c + r) * ld1 + 16 * ks + 8 * (e >> 2) + 4 * lh + (e & 3)], a0, a1, a2);
+            h[e] = a0; m[e] = a1; l[e] = a2;
+        }
+        o = image + c * PT3_W1_B + r * 128 + ((sl ^ ((r >> 1) & 7)) << 4);
+        *reinterpret_cast<bf16x8*>(o) = h;
+        *reinterpret_cast<bf16x8*>(o + 4096) = m;
+        *reinterpret_cast<bf16x8*>(o + 8192) = l;
+    } else {
+        const int idx = (blockIdx.x - 1) * 256 + t, r = idx >> 2, sl = idx & 3, ks = sl >> 1, lh = sl & 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 a0, a1, a2;
+            st_split3(w2[(size_t)r * 128 + 32 * c + 16 * ks + 8 * (e >> 2) + 4 * lh + (e & 3)], a0, a1, a2);
+            h[e] = a0; m[e] = a1; l[e] = a2;
+        }
+        o = image + 4 * PT3_W1_B + c * MS3_W2_B + r * 64 + ((sl ^ ((r >> 2) & 3)) << 4);
+        *reinterpret_cast<bf16x8*>(o) = h;
+        *reinterpret_cast<bf16x8*>(o + 8192) = m;
+        *reinterpret_cast<bf16x8*>(o + 16384) = l;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void pe_tail_split3_kernel(const float* __restrict__ x, const float* __restrict__ tab, const unsigned char* __restrict__ image,
+                                                                const float* __restrict__ b2, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float eps, float* __restrict__ out, const int R, const int P) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)sm3;
+    {
+        // the whole image once: wave w copies bytes [36 864 w, 36 864 (w + 1)) in nine runs of four 1-KiB pieces
+        const i32x4 rsd = make_rsrc(image, (unsigned)PT3_IMAGE_B);
+        const unsigned vlin = (unsigned)lane << 4;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const unsigned o = (unsigned)wave * 36864u + (unsigned)u * 4096u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                         "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds"
+                         : : "s"(lds0 + o), "v"(vlin), "s"(rsd), "s"(o) : "memory");
+        }
+        float* vec = reinterpret_cast<float*>(sm3 + PT3_IMAGE_B);
+        if (tid < 128) { vec[tid] = b2[tid]; vec[128 + tid] = gamma[tid]; vec[256 + tid] = beta[tid]; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const float* vec = reinterpret_cast<const float*>(sm3 + PT3_IMAGE_B) + 4 * lh;
+    const int fo1_row = li * 128, fo1_x = (li >> 1) & 7;
+    int fo2[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fo2[ks] = 4 * PT3_W1_B + li * 64 + (((2 * ks + lh) ^ ((li >> 2) & 3)) << 4);
+    const int nblk = (R + 31) >> 5, stride = (int)gridDim.x * 4;
+    int blk = (int)blockIdx.x * 4 + wave;
+    if (blk >= nblk) return;
+
+    float4 xa[8], tv[16];
+    auto load_block = [&](int b, float4 (&xo)[8], float4 (&to)[16]) {
+        const int row = b * 32 + li;
+        const size_t rowc = (size_t)(row < R ? row : R - 1);
+        const float* xr = x + rowc * 64 + 4 * lh;
+        const float* tr = tab + (size_t)(rowc % (size_t)P) * 128 + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xo[j] = *reinterpret_cast<const float4*>(xr + 8 * j);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) to[j] = *reinterpret_cast<const float4*>(tr + 8 * j);
+    };
+    load_block(blk, xa, tv);
+#define PT3_BF(v) __builtin_bit_cast(bf16x8, v)
+#pragma unroll 1
+    for (; blk < nblk; blk += stride) {
+        const int row = blk * 32 + li;
+        const bool rok = row < R;
+        const size_t rowc = (size_t)(rok ? row : R - 1);
+        u32x4 xp[3][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            ms3_split_pair(xa[j].x, xa[j].y, h0, m0, l0);
+            ms3_split_pair(xa[j].z, xa[j].w, h1, m1, l1);
+            xp[0][j >> 1][2 * (j & 1)] = h0; xp[0][j >> 1][2 * (j & 1) + 1] = h1;
+            xp[1][j >> 1][2 * (j & 1)] = m0; xp[1][j >> 1][2 * (j & 1) + 1] = m1;
+            xp[2][j >> 1][2 * (j & 1)] = l0; xp[2][j >> 1][2 * (j & 1) + 1] = l1;
+        }
+        float4 tc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tc[j] = tv[j];
+        const int nb = blk + stride;
+        if (nb < nblk) load_block(nb, xa, tv);                  // the next block's rows and table values: one block ahead
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 o[4];
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[oc][r] = 0.f;
+        // fc1 chunk 0 (K = 64: four 16-k steps)
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const unsigned char* w1 = sm3 + fo1_row;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                u32x4 f[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(w1 + p * 4096 + (((2 * ks + lh) ^ fo1_x) << 4));
+                MS3_SIX(acc, f, xp[0][ks], xp[1][ks], xp[2][ks])
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            u32x4 hp[3][2];
+            f32x16 an;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) an[r] = 0.f;
+            // table add + ReLU + split of chunk c [under fc1 of chunk c + 1]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (c < 3) {
+                    const unsigned char* w1 = sm3 + (c + 1) * PT3_W1_B + fo1_row;
+                    u32x4 f[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(w1 + p * 4096 + (((2 * ks + lh) ^ fo1_x) << 4));
+                    MS3_SIX(an, f, xp[0][ks], xp[1][ks], xp[2][ks])
+                }
+                {
+                    const float4 t4 = tc[4 * c + ks];            // hidden features 32 c + 8 ks + 4 lh + (0..3): accumulator registers 4 ks .. 4 ks + 3
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    ms3_split_pair(fmaxf(acc[4 * ks] + t4.x, 0.f), fmaxf(acc[4 * ks + 1] + t4.y, 0.f), h0, m0, l0);
+                    ms3_split_pair(fmaxf(acc[4 * ks + 2] + t4.z, 0.f), fmaxf(acc[4 * ks + 3] + t4.w, 0.f), h1, m1, l1);
+                    hp[0][ks >> 1][2 * (ks & 1)] = h0; hp[0][ks >> 1][2 * (ks & 1) + 1] = h1;
+                    hp[1][ks >> 1][2 * (ks & 1)] = m0; hp[1][ks >> 1][2 * (ks & 1) + 1] = m1;
+                    hp[2][ks >> 1][2 * (ks & 1)] = l0; hp[2][ks >> 1][2 * (ks & 1) + 1] = l1;
+                }
+                if (c < 3) { MS3_SCHED_MFMA_VALU(5) MS3_SCHED_MFMA_VALU(5) MS3_SCHED_MFMA_VALU(5) MS3_SCHED_MFMA_VALU(5) MS3_SCHED_MFMA_VALU(5) MS3_SCHED_MFMA_VALU(5) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // fc2: the chunk is the k slice [32 c, 32 c + 32): four accumulator tiles x two 16-k steps
+            {
+                const unsigned char* wc = sm3 + c * MS3_W2_B;
+                u32x4 f[3], fn[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(wc + p * 8192 + fo2[0]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int oc = u >> 1, ks = u & 1, un = u + 1 < 8 ? u + 1 : u;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) fn[p] = *reinterpret_cast<const u32x4*>(wc + p * 8192 + (un >> 1) * 2048 + fo2[un & 1]);
+                    MS3_SIX(o[oc], f, hp[0][ks], hp[1][ks], hp[2][ks])
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) f[p] = fn[p];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            acc = an;
+        }
+        // + b2, LayerNorm over the row's 128 values (lanes li and li + 32 hold them), affine, store
+        float s = 0.f;
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 bb = *reinterpret_cast<const float4*>(vec + oc * 32 + 8 * jj);
+                o[oc][4 * jj] += bb.x; o[oc][4 * jj + 1] += bb.y; o[oc][4 * jj + 2] += bb.z; o[oc][4 * jj + 3] += bb.w;
+                s += (o[oc][4 * jj] + o[oc][4 * jj + 1]) + (o[oc][4 * jj + 2] + o[oc][4 * jj + 3]);
+            }
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / 128.0f);
+        float v = 0.f;
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[oc][r] -= mean; v += o[oc][r] * o[oc][r]; }
+        v += __shfl_xor(v, 32, 64);
+        const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + eps);
+        if (rok) {
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 gg = *reinterpret_cast<const float4*>(vec + 128 + oc * 32 + 8 * jj), be = *reinterpret_cast<const float4*>(vec + 256 + oc * 32 + 8 * jj);
+                    *reinterpret_cast<float4*>(out + rowc * 128 + oc * 32 + 8 * jj + 4 * lh) =
+                        make_float4(o[oc][4 * jj] * rstd * gg.x + be.x, o[oc][4 * jj + 1] * rstd * gg.y + be.y, o[oc][4 * jj + 2] * rstd * gg.z + be.z,
+                                    o[oc][4 * jj + 3] * rstd * gg.w + be.w);
+                }
+        }
+    }
+#undef PT3_BF
+}
+
 #undef MS3_T0
 #undef MS3_T1
 #undef MS3_PHASE2

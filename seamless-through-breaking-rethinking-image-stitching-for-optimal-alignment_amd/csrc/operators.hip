@@ -115,10 +115,12 @@ int st_patch_embed(const float* cost_maps, const float* const* weights, int32_t 
 // st_patch_embed for 64x64 cost maps with the third convolution (Conv2d(32,64,6,2,2), 77 of the operator's 99 GFLOP per pair) on exact-split
 // operands (st_gemm_desc.split3): the fused c0 + c2 launch emits its result as bf16 planes (s2_planes: [3][1][M*256][32], s2_pstride elements
 // apart, no fp32 copy), c4_w_planes = st_split3_pack of c4_w [64, 1152].  M * 256 * 32 * 6 bytes must stay below 2 GiB (M <= 16 384 maps per call).
+// tail_image (st_pe_tail_split3_pack of weights[6] / weights[7]) != NULL: the three launches behind the third convolution (64 -> 128 + position table + ReLU,
+// 128 -> 128 + bias, LayerNorm) run as ONE (st_pe_tail_split3); s4 is then not written and may be NULL.
 int st_patch_embed_split3(const float* cost_maps, const float* const* weights, int32_t ld_f0, const float* pe_bias, void* s2_planes,
                           int64_t s2_pstride, const void* c4_w_planes, int64_t c4_w_pstride, float* s3, float* s4, float* tokens, int32_t M,
-                          int32_t H, int32_t W, void* workspace, int64_t workspace_floats, void* stream) {
-    if (!cost_maps || !weights || !pe_bias || !s2_planes || !c4_w_planes || !s3 || !s4 || !tokens || M <= 0 || H != 64 || W != 64) return ST_EINVAL;
+                          int32_t H, int32_t W, const void* tail_image, int64_t tail_image_bytes, void* workspace, int64_t workspace_floats, void* stream) {
+    if (!cost_maps || !weights || !pe_bias || !s2_planes || !c4_w_planes || !s3 || (!s4 && !tail_image) || !tokens || M <= 0 || H != 64 || W != 64) return ST_EINVAL;
     const int H2 = 16, W2 = 16, H3 = 8, W3 = 8, P = 64;
     ST_TRY(st_patch_conv12_planes(cost_maps, weights[0], weights[1], weights[2], weights[3], s2_planes, s2_pstride, M, H, W, stream));
     {
@@ -127,6 +129,10 @@ int st_patch_embed_split3(const float* cost_maps, const float* const* weights, i
         g.d.split3 = 1; g.d.a_plane_stride = s2_pstride; g.d.a_rows = (int64_t)M * H2 * W2; g.d.w_plane_stride = c4_w_pstride; g.d.w_rows = 64;
         ST_TRY(g.run(stream));
     }
+    if (tail_image)
+        return st_pe_tail_split3(s3, pe_bias, P, tail_image, tail_image_bytes, weights[8], weights[9], weights[10], 1e-5f, tokens, M * P, stream);
+    if (tail_image)
+        return st_pe_tail_split3(s3, pe_bias, P, tail_image, tail_image_bytes, weights[8], weights[9], weights[10], 1e-5f, tokens, M * P, stream);
     ST_TRY(Gemm(s3, 64, weights[6], ld_f0, s4, 128, M * P, 128, 64).aux0(pe_bias, 128, 0, P).act(ST_ACT_RELU)
                .work(workspace, workspace_floats).run(stream));
     ST_TRY(Gemm(s4, 128, weights[7], 128, tokens, 128, M * P, 128, 128).bias(weights[8])

@@ -50,6 +50,7 @@ assert not (SPLIT3 and FORK_ENC), "ST_FORK_ENC is an fp32-path experiment"
 S3_PAIR = os.environ.get("ST_S3_PAIR", "1") != "0"
 S3_PE = os.environ.get("ST_S3_PE", "1") != "0"                 # PatchEmbed's third convolution on planes
 S3_MLP = os.environ.get("ST_S3_MLP", "1") != "0"               # the C = 128 block tails (st_mlp128) on the split3 kernel (st_mlp128_split3, weights packed into its image once)
+S3_PE_TAIL = os.environ.get("ST_S3_PE_TAIL", "1") != "0"       # PatchEmbed's ffn_with_coord + LayerNorm (three HBM-bound launches over M P rows) as one split3 launch
 S3_LIN = os.environ.get("ST_S3_LIN", "1") != "0"               # LayerNorm -> q | k | v projection (K = 128, N = 384) on the split3 row kernel (st_rowlin128_split3)
 S3_CHAIN = os.environ.get("ST_S3_CHAIN", "1") != "0"           # the latent layers' 128-wide tails (st_linear_chain128) on the same split3 kernel, hidden = 128
 S3_AGG = os.environ.get("ST_S3_AGG", "0") == "1"               # GMA aggregate on planes (measured equal to the fp32 kernel in the chain: HBM-bound; default off)
@@ -155,6 +156,8 @@ class FlowFormer(ParamTree):
                          pe["f0"][0], pe["f2"][0], pe["f2"][1], pe["norm"][0], pe["norm"][1]]
         if SPLIT3 and pe["c4"][0].is_cuda:               # (a pack on the CPU -- layout tests -- has no planes: the module cannot run there anyway)
             pe["c4_s3"] = ops.split3_pack(pe["c4"][0])          # [64, 36 taps * 32]: the split3 form of PatchEmbed's third convolution
+            if S3_PE_TAIL:
+                pe["tail_s3"] = ops.pe_tail_split3_pack(pe["f0"][0], pe["f2"][0])       # ffn_with_coord (64 -> 128 -> 128) + LayerNorm as one launch
         pk["pe"] = pe
         pk["latents"] = p[c + "latent_tokens"][0].contiguous()
 
@@ -379,7 +382,7 @@ class FlowFormer(ParamTree):
             for m0 in range(0, M, CH):
                 m1 = min(M, m0 + CH)
                 ops.patch_embed_split3(cost_maps[m0:m1], pe["embed11"], pe["f0"][0].stride(0), self._const[key], s2p, pe["c4_s3"],
-                                       s3[m0 * P:m1 * P], s4[m0 * P:m1 * P], f[m0 * P:m1 * P], m1 - m0, H2, W2)
+                                       s3[m0 * P:m1 * P], s4[m0 * P:m1 * P], f[m0 * P:m1 * P], m1 - m0, H2, W2, tail_image=pe.get("tail_s3"))
             return f, P
         s1 = None if (H2 == 64 and W2 == 64 and FUSE_PE) else _new(M * H1 * W1, 16, dev)
         s2 = _new(M * H2p * W2p, 32, dev)

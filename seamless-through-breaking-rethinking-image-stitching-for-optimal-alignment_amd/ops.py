@@ -509,11 +509,32 @@ def patch_embed(cost_maps, weights11, ld_f0, pe_bias, s1, s2, s3, s4, tokens, M,
     return tokens
 
 
-def patch_embed_split3(cost_maps, weights11, ld_f0, pe_bias, s2_planes, c4_w_planes, s3, s4, tokens, M, H, W):
-    """patch_embed for 64 x 64 maps with the third convolution on exact-split operands (st_patch_embed_split3); s2_planes = Planes(M*256, 32)."""
+def pe_tail_split3_pack(w_f0, w_f2):
+    """ffn_with_coord.0's first 64 input columns [128, ld] + ffn_with_coord.2 [128, 128] -> the LDS image of st_pe_tail_split3 (uint8 tensor; pack once per weight load)"""
+    assert w_f0.shape[0] == 128 and w_f0.shape[1] >= 64 and w_f0.stride(1) == 1 and w_f2.shape == (128, 128) and w_f2.is_contiguous()
+    nb = C.c_int64(0)
+    check(lib.st_pe_tail_split3_image_bytes(C.byref(nb)), "st_pe_tail_split3_image_bytes")
+    img = torch.empty(nb.value, dtype=torch.uint8, device=w_f0.device)
+    check(lib.st_pe_tail_split3_pack(_p(w_f0), w_f0.stride(0), _p(w_f2), C.c_void_p(img.data_ptr()), nb.value, _stream()), "st_pe_tail_split3_pack")
+    return img
+
+
+def pe_tail_split3(x, tab, image, b2, gamma, beta, out, eps=1e-5):
+    """out[R,128] = LayerNorm(ReLU(x[R,64] @ w1^T + tab[r % P]) @ w2^T + b2) (st_pe_tail_split3)"""
+    assert x.shape[1] == 64 and x.is_contiguous() and out.shape == (x.shape[0], 128) and out.is_contiguous() and tab.shape[1] == 128 and tab.is_contiguous()
+    check(lib.st_pe_tail_split3(_p(x), _p(tab), tab.shape[0], C.c_void_p(image.data_ptr()), image.numel(), _p(b2), _p(gamma), _p(beta), float(eps), _p(out),
+                                x.shape[0], _stream()), "st_pe_tail_split3")
+    return out
+
+
+def patch_embed_split3(cost_maps, weights11, ld_f0, pe_bias, s2_planes, c4_w_planes, s3, s4, tokens, M, H, W, tail_image=None):
+    """patch_embed for 64 x 64 maps with the third convolution on exact-split operands (st_patch_embed_split3); s2_planes = Planes(M*256, 32);
+    tail_image (pe_tail_split3_pack): the three launches behind it as one (s4 may then be None)."""
     arr = (C.c_void_p * 11)(*[w.data_ptr() for w in weights11])
     check(lib.st_patch_embed_split3(_pc(cost_maps), arr, ld_f0, _pc(pe_bias), C.c_void_p(s2_planes.ptr()), s2_planes.pstride, C.c_void_p(c4_w_planes.ptr()),
-                                    c4_w_planes.pstride, _pc(s3), _pc(s4), _pc(tokens), M, H, W, *_ws(cost_maps.device), _stream()), "st_patch_embed_split3")
+                                    c4_w_planes.pstride, _pc(s3), _pc(s4) if s4 is not None else None, _pc(tokens), M, H, W,
+                                    C.c_void_p(tail_image.data_ptr()) if tail_image is not None else None, tail_image.numel() if tail_image is not None else 0,
+                                    *_ws(cost_maps.device), _stream()), "st_patch_embed_split3")
     return tokens
 
 

@@ -421,3 +421,32 @@ def test_rowlin128_split3(ops, M, N, ln):
         assert ((o2.cpu().double() - F.linear(xd, w.double())).abs().max() / scale).item() < 3e-6      # (measured 1.2e-6: a maximum over 12 288 values against the rms scale)
         with pytest.raises(ops.StitchErrorBase):
             ops.rowlin128_split3(dev(x), torch.empty(M, N + 32, device="cuda"), img)                    # image packed for fewer output features
+
+
+@pytest.mark.parametrize("R,P", [(64 * 70, 64), (40001, 64), (96, 32), (17, 5)])
+def test_pe_tail_split3(ops, R, P):
+    """st_pe_tail_split3: PatchEmbed's tail (encoder.py:77-95) -- ffn_with_coord.0 on [x | pe(pos)] (the position half folded into a per-position
+    table), ReLU, ffn_with_coord.2, LayerNorm -- as one launch with both products as six-product bf16 contractions, the weights held in LDS.
+    Against fp64 torch and against the three fp32 launches it replaces (error bounded by 1.25x theirs); ragged row counts, table periods that do
+    not divide the 32-row blocks."""
+    gg = g(31)
+    x = torch.randn(R, 64, generator=gg)
+    w1, tab = torch.randn(128, 128, generator=gg) / 128 ** 0.5, torch.randn(P, 128, generator=gg) * 0.5
+    w2, b2 = torch.randn(128, 128, generator=gg) / 128 ** 0.5, torch.randn(128, generator=gg) * 0.1
+    gam, bet = torch.rand(128, generator=gg) + 0.5, torch.randn(128, generator=gg) * 0.1
+    rows = torch.arange(R) % P
+    h = torch.relu(x.double() @ w1[:, :64].double().t() + tab.double()[rows])
+    ref = F.layer_norm(h @ w2.double().t() + b2.double(), (128,), gam.double(), bet.double(), 1e-5)
+    # the three fp32 launches
+    s4, tok = torch.empty(R, 128, device="cuda"), torch.empty(R, 128, device="cuda")
+    ops.conv_gemm(dev(x), dev(w1)[:, :64], s4, aux0=dev(tab), row_mod=P, act="relu")
+    ops.conv_gemm(s4, dev(w2), tok, bias=dev(b2))
+    ops.layernorm(tok, dev(gam), dev(bet), tok, 1e-5)
+    out = torch.full((R + 1, 128), 7.0, device="cuda")
+    img = ops.pe_tail_split3_pack(dev(w1), dev(w2))
+    ops.pe_tail_split3(dev(x), dev(tab), img, dev(b2), dev(gam), dev(bet), out[:R])
+    assert (out[R] == 7.0).all()
+    scale = ref.pow(2).mean().sqrt().item()
+    ee, es = (tok.cpu().double() - ref), (out[:R].cpu().double() - ref)
+    check(f"pe_tail_split3_rms_vs_fp64_{R}_{P}", es.pow(2).mean().sqrt().item() / scale, 1.25 * ee.pow(2).mean().sqrt().item() / scale)
+    check(f"pe_tail_split3_max_vs_fp64_{R}_{P}", es.abs().max().item() / scale, max(2.0 * ee.abs().max().item() / scale, 5e-7))
