@@ -55,7 +55,7 @@ tools/probes/_bin/mbc > gpurun_out/${TAG}_mfma_bf16_chain.txt 2>/dev/null
 tail -n 3 gpurun_out/${TAG}_mfma_utilisation.txt
 python tools/bench_out_harness.py 48 2>/dev/null | grep '^{' > gpurun_out/${TAG}_out_harness.json; cat gpurun_out/${TAG}_out_harness.json
 # same-box A/B of the round's switches (each configuration twice)
-bash tools/r6_ab.sh "ST_SPLIT3=0" "ST_SPLIT3=1 ST_S3_MLP=0 ST_SPLIT3_KPAR=0 ST_S3_LIN=0 ST_S3_CHAIN=0" "ST_SPLIT3=1 ST_SPLIT3_KPAR=0 ST_S3_LIN=0 ST_S3_CHAIN=0" "ST_SPLIT3=1 ST_S3_LIN=0 ST_S3_CHAIN=0" "ST_SPLIT3=1" > gpurun_out/${TAG}_ab_switches.txt 2>/dev/null; cat gpurun_out/${TAG}_ab_switches.txt
+bash tools/r6_ab.sh "ST_SPLIT3=0" "ST_SPLIT3=1 ST_S3_MLP=0 ST_SPLIT3_KPAR=0 ST_S3_LIN=0 ST_S3_CHAIN=0 ST_S3_PE_TAIL=0" "ST_SPLIT3=1 ST_SPLIT3_KPAR=0 ST_S3_LIN=0 ST_S3_CHAIN=0 ST_S3_PE_TAIL=0" "ST_SPLIT3=1 ST_S3_LIN=0 ST_S3_CHAIN=0 ST_S3_PE_TAIL=0" "ST_SPLIT3=1 ST_S3_PE_TAIL=0" "ST_SPLIT3=1" > gpurun_out/${TAG}_ab_switches.txt 2>/dev/null; cat gpurun_out/${TAG}_ab_switches.txt
 python bench.py 2>>gpurun_out/${TAG}_bench.err | grep '^{' > gpurun_out/${TAG}_bench.json
 # 2-rank rehearsal of the launcher / sharding / all-gather on the 1-GPU box (both ranks on cuda:0, gloo): bounded, last
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --share-gpu --steps 40 --warmup 6 --no-cpu-baseline --no-corr-roofline --harness-pairs 48 2>gpurun_out/${TAG}_bench_2rank.err | grep '^{' > gpurun_out/${TAG}_bench_2rank_gloo_share_gpu.json

@@ -15,7 +15,7 @@ for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
         continue
     ms = float(r["TotalDurationNs"]) / fw / 1e6
     tot += ms
-    if any(k in r["Name"] for k in ("conv_gemm", "rowstream_gemm", "rowchain128", "rowmlp128", "rowlin128", "splitk_reduce", "narrow_conv", "skinny_gemm", "patch_c0c2")):
+    if any(k in r["Name"] for k in ("conv_gemm", "rowstream_gemm", "rowchain128", "rowmlp128", "rowlin128", "pe_tail_split3", "splitk_reduce", "narrow_conv", "skinny_gemm", "patch_c0c2")):
         gemm += ms
     if ms >= 0.004:
         print(f"{ms:8.3f} ms  x{int(r['Calls']) / fw:7.1f}  avg {float(r['AverageNs']) / 1e3:8.1f} us  {short(r['Name'])}")
