@@ -1695,8 +1695,13 @@ extern "C" int st_pe_tail_split3(const float* x, const float* tab, int32_t P, co
     const int nblk = (R + 31) / 32;
     int G = (nblk + 3) / 4;
     if (G > 256) G = 256;                                       // 146 KB of LDS: one workgroup per CU
+    // a grid whose row stride (G * 128) is a multiple of the table period keeps a wave's table rows the same for all its blocks: the largest such G <= 256
+    bool tabinv = false;
+    for (int g = G; g >= (G > 8 ? G - G / 8 : 1); --g)
+        if (((long)g * 128) % P == 0) { G = g; tabinv = true; break; }
     const size_t lds = (size_t)PT3_IMAGE_B + PT3_VEC_B;
-    (void)hipFuncSetAttribute((const void*)pe_tail_split3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = tabinv ? pe_tail_split3_kernel<true> : pe_tail_split3_kernel<false>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     st_gemm_observer_fn obs = g_observer;
     st_gemm_desc od;
     if (obs) {                                                  // reported as R x 192 x 128: its FLOPs (2 R (128 . 64 + 128 . 128))
@@ -1707,7 +1712,7 @@ extern "C" int st_pe_tail_split3(const float* x, const float* tab, int32_t P, co
         obs(&od, stream, 0, g_observer_user);
     }
     g_last_plan[0] = 11; g_last_plan[1] = 41; g_last_plan[2] = 1; g_last_plan[3] = 1;
-    hipLaunchKernelGGL(pe_tail_split3_kernel, dim3(G), dim3(256), lds, (hipStream_t)stream, x, tab, (const unsigned char*)image, b2, gamma, beta, eps, out, (int)R, (int)P);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, (hipStream_t)stream, x, tab, (const unsigned char*)image, b2, gamma, beta, eps, out, (int)R, (int)P);
     if (obs) obs(&od, stream, 1, g_observer_user);
     ST_CHECK_LAUNCH();
     return ST_OK;

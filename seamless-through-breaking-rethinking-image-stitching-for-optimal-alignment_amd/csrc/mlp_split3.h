@@ -618,6 +618,9 @@ __global__ __launch_bounds__(256) void pe_tail_split3_pack_kernel(const float* _
     }
 }
 
+// TABINV: the table rows of a wave's blocks are the same for every block (the host picks a grid with (gridDim.x * 128) % P == 0): loaded once, and the loop
+// holds only the eight row loads of the next block and the sixteen stores of the current one
+template <bool TABINV>
 __global__ __launch_bounds__(256, 1) void pe_tail_split3_kernel(const float* __restrict__ x, const float* __restrict__ tab, const unsigned char* __restrict__ image,
                                                                 const float* __restrict__ b2, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float eps, float* __restrict__ out, const int R, const int P) {
@@ -654,17 +657,20 @@ __global__ __launch_bounds__(256, 1) void pe_tail_split3_kernel(const float* __r
     if (blk >= nblk) return;
 
     float4 xa[8], tv[16];
-    auto load_block = [&](int b, float4 (&xo)[8], float4 (&to)[16]) {
+    auto load_rows = [&](int b, float4 (&xo)[8]) {
         const int row = b * 32 + li;
-        const size_t rowc = (size_t)(row < R ? row : R - 1);
-        const float* xr = x + rowc * 64 + 4 * lh;
-        const float* tr = tab + (size_t)(rowc % (size_t)P) * 128 + 4 * lh;
+        const float* xr = x + (size_t)(row < R ? row : R - 1) * 64 + 4 * lh;
 #pragma unroll
         for (int j = 0; j < 8; ++j) xo[j] = *reinterpret_cast<const float4*>(xr + 8 * j);
+    };
+    auto load_table = [&](int b, float4 (&to)[16]) {
+        const int row = b * 32 + li;            // (rows past R: the table row of their own index -- the same row in every block of the wave, never stored)
+        const float* tr = tab + (size_t)(row % P) * 128 + 4 * lh;
 #pragma unroll
         for (int j = 0; j < 16; ++j) to[j] = *reinterpret_cast<const float4*>(tr + 8 * j);
     };
-    load_block(blk, xa, tv);
+    load_rows(blk, xa);
+    load_table(blk, tv);
 #define PT3_BF(v) __builtin_bit_cast(bf16x8, v)
 #pragma unroll 1
     for (; blk < nblk; blk += stride) {
@@ -684,8 +690,11 @@ __global__ __launch_bounds__(256, 1) void pe_tail_split3_kernel(const float* __r
         float4 tc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) tc[j] = tv[j];
+        // the next block's rows, one block ahead -- UNCONDITIONALLY (the last block re-reads itself): behind a branch the compiler has two paths to merge
+        // and waits for vmcnt(0) at the loop top, i.e. for the sixteen stores of the previous block as well
         const int nb = blk + stride;
-        if (nb < nblk) load_block(nb, xa, tv);                  // the next block's rows and table values: one block ahead
+        load_rows(nb < nblk ? nb : blk, xa);
+        if (!TABINV) load_table(nb < nblk ? nb : blk, tv);
         __builtin_amdgcn_sched_barrier(0);
         f32x16 o[4];
 #pragma unroll
@@ -698,12 +707,18 @@ __global__ __launch_bounds__(256, 1) void pe_tail_split3_kernel(const float* __r
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         {
             const unsigned char* w1 = sm3 + fo1_row;
+            u32x4 f[3], fn[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(w1 + p * 4096 + (((0 + lh) ^ fo1_x) << 4));
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                u32x4 f[3];
+                const int kn = ks + 1 < 4 ? ks + 1 : ks;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(w1 + p * 4096 + (((2 * ks + lh) ^ fo1_x) << 4));
+                for (int p = 0; p < 3; ++p) fn[p] = *reinterpret_cast<const u32x4*>(w1 + p * 4096 + (((2 * kn + lh) ^ fo1_x) << 4));
                 MS3_SIX(acc, f, xp[0][ks], xp[1][ks], xp[2][ks])
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[p] = fn[p];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -713,15 +728,22 @@ __global__ __launch_bounds__(256, 1) void pe_tail_split3_kernel(const float* __r
             f32x16 an;
 #pragma unroll
             for (int r = 0; r < 16; ++r) an[r] = 0.f;
-            // table add + ReLU + split of chunk c [under fc1 of chunk c + 1]
+            // table add + ReLU + split of chunk c [under fc1 of chunk c + 1, its fragments read one 16-k step ahead]
+            u32x4 g1[3], g1n[3];
+            if (c < 3) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) g1[p] = *reinterpret_cast<const u32x4*>(sm3 + (c + 1) * PT3_W1_B + fo1_row + p * 4096 + (((0 + lh) ^ fo1_x) << 4));
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 if (c < 3) {
                     const unsigned char* w1 = sm3 + (c + 1) * PT3_W1_B + fo1_row;
-                    u32x4 f[3];
+                    const int kn = ks + 1 < 4 ? ks + 1 : ks;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const u32x4*>(w1 + p * 4096 + (((2 * ks + lh) ^ fo1_x) << 4));
-                    MS3_SIX(an, f, xp[0][ks], xp[1][ks], xp[2][ks])
+                    for (int p = 0; p < 3; ++p) g1n[p] = *reinterpret_cast<const u32x4*>(w1 + p * 4096 + (((2 * kn + lh) ^ fo1_x) << 4));
+                    MS3_SIX(an, g1, xp[0][ks], xp[1][ks], xp[2][ks])
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) g1[p] = g1n[p];
                 }
                 {
                     const float4 t4 = tc[4 * c + ks];            // hidden features 32 c + 8 ks + 4 lh + (0..3): accumulator registers 4 ks .. 4 ks + 3
